@@ -1,0 +1,614 @@
+// CPU oracle, post-processing and matcher half (TEST INFRASTRUCTURE ONLY — see ppg_oracle.h).
+//
+// Line-by-line restatement of
+//   feature/src/PPGExtractor.cpp:158-234 (detectKeyPoint), :236-442 (detectLines),
+//   :461-513 (heatMapInlierRate / heatMapLineScore), :515-538 (genPointDescriptor),
+//   :540-589 (refineHeatMap / bilinearInterpolation);
+//   feature/src/MapPoint.cpp:22-29 (DescriptorDistance);
+//   map/src/Frame.cpp:138-156, 262-327 and sensors/src/GeometricCamera.cpp:26-61 (grid);
+//   matching/src/Matcher.cpp:203-381 (ExtendMapMatches), :582-651 (SearchForInitialization).
+// Compiled with -ffp-contract=off and without FMA code generation so that every float
+// expression rounds as the reference's (-O3, no -march) build does.  The reference's C++ cannot be
+// built here (OpenCV, Eigen, DBoW3, LibTorch absent), so this half is "parity unpinned" against a
+// running reference; the third-party pieces (cv::undistortPoints) follow OpenCV's published
+// algorithm and reduce to the identity for D = 0, the only case the parity tests use.
+#include "ppg_oracle.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <numeric>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+namespace {
+const double kPi = 3.1415926535897932384626433832795;  // CV_PI
+const double k2Pi = 6.283185307179586476925286766559;  // CV_2PI
+const float kInvSampleGap[4] = {0.3333f, 0.200f, 0.1427f, 0.1111f};  // PPGExtractor.cpp:19
+const float TH_HIGH = 0.8f, TH_LOW = 0.7f;                            // Matcher.cpp:12-13
+
+// cv::undistortPoints(src, dst, K, D(4), noArray(), P = K): 5 fixed-point iterations in double.
+void undistort_pinhole(const ppgo_cfg* c, float x, float y, float* ou, float* ov) {
+    const double fx = c->K[0], fy = c->K[4], cx = c->K[2], cy = c->K[5];
+    const double k1 = c->D[0], k2 = c->D[1], p1 = c->D[2], p2 = c->D[3];
+    double xn = (x - cx) * (1.0 / fx), yn = (y - cy) * (1.0 / fy);
+    const double x0 = xn, y0 = yn;
+    for (int j = 0; j < 5; j++) {
+        double r2 = xn * xn + yn * yn;
+        double icdist = 1.0 / (1.0 + ((0.0 * r2 + k2) * r2 + k1) * r2);
+        if (icdist < 0) { xn = x0; yn = y0; break; }
+        double dX = 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn);
+        double dY = p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn;
+        xn = (x0 - dX) * icdist;
+        yn = (y0 - dY) * icdist;
+    }
+    *ou = (float)(fx * xn + cx);
+    *ov = (float)(fy * yn + cy);
+}
+
+// cv::fisheye::undistortPoints(src, dst, K, D, noArray(), P = K): Newton on theta, 10 iterations.
+void undistort_fisheye(const ppgo_cfg* c, float x, float y, float* ou, float* ov) {
+    const double fx = c->K[0], fy = c->K[4], cx = c->K[2], cy = c->K[5];
+    const double k0 = c->D[0], k1 = c->D[1], k2 = c->D[2], k3 = c->D[3];
+    double px = (x - cx) / fx, py = (y - cy) / fy;
+    double theta_d = std::sqrt(px * px + py * py);
+    theta_d = std::min(std::max(-kPi / 2., theta_d), kPi / 2.);
+    double scale = 0.0;
+    if (theta_d > 1e-8) {
+        double theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+            double k0t2 = k0 * t2, k1t4 = k1 * t4, k2t6 = k2 * t6, k3t8 = k3 * t8;
+            double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) /
+                         (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+            theta = theta - fix;
+            if (std::fabs(fix) < 1e-8) break;
+        }
+        scale = std::tan(theta) / theta_d;
+    } else {
+        scale = 1.0;
+    }
+    double ux = px * scale, uy = py * scale;
+    *ou = (float)(fx * ux + cx);
+    *ov = (float)(fy * uy + cy);
+}
+
+struct Edge {
+    unsigned s, e;
+    bool bad;
+    float lscore;
+    unsigned other(unsigned pid) const { return pid == s ? e : s; }
+};
+
+struct LineCtx {
+    const ppgo_cfg* c;
+    const float* heat;
+    int W;
+    float invScale;
+    float at(int y, int x) const { return heat[(size_t)y * W + x]; }
+};
+
+// PPGExtractor.cpp:580-589
+float bilinear(const LineCtx& L, float ptX, float ptY) {
+    int x1 = (int)ptX, x2 = x1 + 1, y1 = (int)ptY, y2 = y1 + 1;
+    float d1 = (x2 - ptX) * L.at(y1, x1) + (ptX - x1) * L.at(y1, x2);
+    float d2 = (x2 - ptX) * L.at(y2, x1) + (ptX - x1) * L.at(y2, x2);
+    return (y2 - ptY) * d1 + (ptY - y1) * d2;
+}
+
+inline float norm2(float dx, float dy) { return std::sqrt(dx * dx + dy * dy); }
+
+// PPGExtractor.cpp:484-497
+float inlier_rate(const LineCtx& L, const float* ps, const float* pe) {
+    float dist = norm2(ps[0] - pe[0], ps[1] - pe[1]);
+    int lenLevel = (int)(dist * L.invScale * 4.0);
+    int segNum = (int)(dist * kInvSampleGap[lenLevel]);
+    float step = (float)(1.0 / (float)segNum);
+    int inl = 0;
+    for (int i = 1; i < segNum; i++) {
+        float sx = ps[0] * step * (float)i + pe[0] * step * (float)(segNum - i);
+        float sy = ps[1] * step * (float)i + pe[1] * step * (float)(segNum - i);
+        int px = (int)(sx + 0.5), py = (int)(sy + 0.5);
+        if (L.at(py, px) > L.c->line_heatmap_thresh) inl++;
+    }
+    return (float)inl / (float)(segNum - 1);
+}
+
+// PPGExtractor.cpp:500-513
+float line_score(const LineCtx& L, const float* ps, const float* pe) {
+    float dist = norm2(ps[0] - pe[0], ps[1] - pe[1]);
+    int lenLevel = (int)(dist * L.invScale * 4.0);
+    int segNum = (int)(dist * kInvSampleGap[lenLevel]);
+    float step = (float)(1.0 / (float)segNum);
+    float sum = 0.f;
+    for (int i = 1; i < segNum; i++) {
+        float sx = ps[0] * step * (float)i + pe[0] * step * (float)(segNum - i);
+        float sy = ps[1] * step * (float)i + pe[1] * step * (float)(segNum - i);
+        sum += bilinear(L, sx, sy);
+    }
+    return sum / (float)(segNum - 1);
+}
+
+// PPGExtractor.cpp:540-578 on the sub-rectangle [y0,y1) x [x0,x1)
+void refine_tile(const ppgo_cfg* c, float* heat, int W, int y0, int y1, int x0, int x1) {
+    std::vector<float> vals;
+    const int segH = y1 - y0, segW = x1 - x0;
+    for (int i = y0; i < y1; i++)
+        for (int j = x0; j < x1; j++)
+            if (heat[(size_t)i * W + j] > c->line_valid_thresh) vals.push_back(heat[(size_t)i * W + j]);
+    int valCount = (int)(c->line_valid_ratio * vals.size());
+    if (valCount < 1) return;
+    if (vals.size() >= segH * segW * 0.9 && vals[(size_t)(vals.size() * 0.9)] > 0.1) {
+        for (int i = y0; i < y1; i++)
+            for (int j = x0; j < x1; j++) heat[(size_t)i * W + j] = 0.f;
+        return;
+    }
+    std::sort(vals.begin(), vals.end(), [](float a, float b) { return a > b; });
+    float ave = std::accumulate(vals.begin(), vals.begin() + valCount, 0.0) / (float)valCount;
+    for (int i = y0; i < y1; i++)
+        for (int j = x0; j < x1; j++) {
+            float cur = heat[(size_t)i * W + j];
+            if (cur > c->line_valid_thresh) {
+                float ns = cur / ave;
+                heat[(size_t)i * W + j] = ns > 1.0 ? 1.0 : ns;
+            } else {
+                heat[(size_t)i * W + j] = 0;
+            }
+        }
+}
+}  // namespace
+
+struct ppgo_grid {
+    int minX, minY, maxX, maxY;
+    float invW, invH;
+    int n;
+    std::vector<float> pos;
+    std::vector<int32_t> cell[64][48];  // FRAME_GRID_COLS x FRAME_GRID_ROWS (GeometricCamera.h:79-80)
+};
+
+extern "C" {
+
+void ppgo_default_cfg(ppgo_cfg* c, int width, int height) {
+    memset(c, 0, sizeof(*c));
+    c->width = width; c->height = height;
+    c->K[0] = 458.654f; c->K[4] = 457.296f; c->K[2] = width * 0.5f; c->K[5] = height * 0.5f; c->K[8] = 1.f;
+    c->desc_dim = 256;
+    c->junction_thresh = 1.0f / 128.0f;
+    c->junction_nms_radius = 4;
+    c->junction_max_num = 500;
+    c->line_valid_thresh = 1.0e-2f;
+    c->line_valid_ratio = 0.3f;
+    c->line_dist_thresh = 2.0f;
+    c->heatmap_refine_sz = 16;
+    c->line_heatmap_thresh = 0.2f;
+    c->line_inlier_rate = 0.8f;
+    c->stable_sort = 1;
+}
+
+int ppgo_detect_keypoints(const ppgo_cfg* c, const float* score, int32_t* kp_xy, float* kp_score,
+                          float* kp_un, uint8_t* kp_out) {
+    const int W = c->width, H = c->height, R = c->junction_nms_radius;
+    std::vector<std::tuple<unsigned, unsigned, float>> pts;
+    pts.reserve((size_t)(0.2 * H * W));
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            float s = score[(size_t)i * W + j];
+            if (s < c->junction_thresh) continue;
+            pts.emplace_back(j, i, s);
+        }
+    if (c->stable_sort) {
+        std::sort(pts.begin(), pts.end(), [W](const auto& a, const auto& b) {
+            if (std::get<2>(a) != std::get<2>(b)) return std::get<2>(a) > std::get<2>(b);
+            return std::get<1>(a) * (unsigned)W + std::get<0>(a) < std::get<1>(b) * (unsigned)W + std::get<0>(b);
+        });
+    } else {
+        std::sort(pts.begin(), pts.end(), [](auto a, auto b) { return std::get<2>(a) > std::get<2>(b); });
+    }
+    std::vector<unsigned char> flag((size_t)W * H, 0);
+    int n = 0;
+    for (auto& kp : pts) {
+        int px = std::get<0>(kp), py = std::get<1>(kp);
+        if (px < R || px > (W - R - 1) || py < R || py > (H - R - 1) || flag[(size_t)py * W + px] != 0) continue;
+        flag[(size_t)py * W + px] = 1;
+        kp_xy[2 * n] = px; kp_xy[2 * n + 1] = py; kp_score[n] = std::get<2>(kp);
+        n++;
+        if ((unsigned)n + 1 > c->junction_max_num) break;
+        for (int i = py - R; i <= py + R; i++)
+            for (int j = px - R; j <= px + R; j++) {
+                if (i < 0 || i > H || j < 0 || j > W) continue;
+                flag[(size_t)i * W + j] = (unsigned char)-1;
+            }
+    }
+    for (int i = 0; i < n; i++) {
+        float u, v;
+        if (c->fisheye) undistort_fisheye(c, (float)kp_xy[2 * i], (float)kp_xy[2 * i + 1], &u, &v);
+        else undistort_pinhole(c, (float)kp_xy[2 * i], (float)kp_xy[2 * i + 1], &u, &v);
+        kp_out[i] = !(u >= 1 && u < W - 1 && v >= 1 && v < H - 1);
+        kp_un[2 * i] = u; kp_un[2 * i + 1] = v;
+    }
+    return n;
+}
+
+void ppgo_refine_heat(const ppgo_cfg* c, float* heat) {
+    const int W = c->width, H = c->height, S = c->heatmap_refine_sz;
+    const int gx = W / S, gy = H / S;
+    for (int i = 0; i < gy; i++)
+        for (int j = 0; j < gx; j++) {
+            int h0 = i * S, w0 = j * S;
+            int h1 = i == (gy - 1) ? H : (i + 1) * S;
+            int w1 = j == (gx - 1) ? W : (j + 1) * S;
+            refine_tile(c, heat, W, h0, h1, w0, w1);
+        }
+}
+
+int ppgo_detect_lines(const ppgo_cfg* c, const float* heat, int n, const float* kp_un, const uint8_t* kp_out,
+                      uint32_t* edge_idx, float* edge_score, int edge_cap,
+                      int32_t* conn_off, uint32_t* conn_idx,
+                      int32_t* coline_off, uint32_t* coline_pairs, int coline_cap) {
+    const int W = c->width, H = c->height;
+    LineCtx L{c, heat, W, 1.0f / std::sqrt((float)(H * H + W * W))};
+    const unsigned N = (unsigned)n;
+    std::vector<float> distMat((size_t)N * N, 0.f), dirMat((size_t)N * N, 0.f);
+    auto P = [&](unsigned i, int k) { return kp_un[2 * i + k]; };
+    for (unsigned i = 0; i < N; i++) {
+        if (kp_out[i]) continue;
+        for (unsigned j = i + 1; j < N; j++) {
+            if (kp_out[j]) continue;
+            float vx = P(j, 0) - P(i, 0), vy = P(j, 1) - P(i, 1);
+            float dist = norm2(vx, vy);
+            vx = vx / dist; vy = vy / dist;
+            distMat[(size_t)i * N + j] = dist;
+            distMat[(size_t)j * N + i] = dist;
+            float d = std::atan2(vy, vx);
+            dirMat[(size_t)i * N + j] = d;
+            float r = (float)(d - kPi);
+            if (r < -kPi) r = (float)(r + k2Pi);
+            dirMat[(size_t)j * N + i] = r;
+        }
+    }
+    std::vector<Edge> cand;
+    std::vector<std::vector<unsigned>> conn(N);
+    const float T = c->line_heatmap_thresh;
+    auto overlap_pass = [&](unsigned a, unsigned b) -> bool {
+        // PPGExtractor.cpp:316-335 with (i,j) = (a,b); :338-357 with (a,b) = (j,i)
+        bool isOverlap = false;
+        for (unsigned lid : conn[a]) {
+            Edge& old = cand[lid];
+            if (old.bad) continue;
+            unsigned pid_old = old.other(a);
+            float ad = dirMat[(size_t)a * N + b] - dirMat[(size_t)a * N + pid_old];
+            if (ad < -kPi) ad = (float)(ad + k2Pi);
+            if (ad > kPi) ad = (float)(ad - k2Pi);
+            ad = std::fabs(ad);
+            if (ad > 0.2 * kPi) continue;
+            float dNew = distMat[(size_t)a * N + b], dOld = distMat[(size_t)a * N + pid_old];
+            float s = std::sin(ad);
+            if (dNew <= dOld && dNew * s < c->line_dist_thresh) old.bad = true;
+            if (dOld < dNew && dOld * s < c->line_dist_thresh) isOverlap = true;
+        }
+        return isOverlap;
+    };
+    for (unsigned i = 0; i < N; i++) {
+        if (kp_out[i]) continue;
+        for (unsigned j = i + 1; j < N; j++) {
+            if (kp_out[j]) continue;
+            float c1x = P(j, 0) * 0.2f + P(i, 0) * 0.8f, c1y = P(j, 1) * 0.2f + P(i, 1) * 0.8f;
+            float c2x = P(j, 0) * 0.8f + P(i, 0) * 0.2f, c2y = P(j, 1) * 0.8f + P(i, 1) * 0.2f;
+            float c3x = P(j, 0) * 0.5f + P(i, 0) * 0.5f, c3y = P(j, 1) * 0.5f + P(i, 1) * 0.5f;
+            if (L.at((int)(c1y + 0.5), (int)(c1x + 0.5)) < T) continue;
+            if (L.at((int)(c2y + 0.5), (int)(c2x + 0.5)) < T) continue;
+            if (L.at((int)(c3y + 0.5), (int)(c3x + 0.5)) < T) continue;
+            if (overlap_pass(i, j)) continue;
+            if (overlap_pass(j, i)) continue;
+            cand.push_back(Edge{i, j, false, 0.f});
+            unsigned lid = (unsigned)cand.size() - 1;
+            conn[i].push_back(lid);
+            conn[j].push_back(lid);
+        }
+    }
+    for (auto& v : conn) v.clear();
+    for (unsigned i = 0; i < cand.size(); i++) {
+        Edge& kl = cand[i];
+        if (kl.bad) continue;
+        const float* ps = &kp_un[2 * kl.s];
+        const float* pe = &kp_un[2 * kl.e];
+        float si = inlier_rate(L, ps, pe);
+        if (si < c->line_inlier_rate) { kl.bad = true; continue; }
+        float sh = line_score(L, ps, pe);
+        if (sh < c->line_heatmap_thresh) { kl.bad = true; continue; }
+        kl.lscore = si * sh;
+        conn[kl.s].push_back(i);
+        conn[kl.e].push_back(i);
+    }
+    // collinear pairs, PPGExtractor.cpp:392-432
+    int ncol = 0;
+    for (unsigned p = 0; p < N; p++) {
+        coline_off[p] = ncol;
+        std::vector<unsigned> idx = conn[p];
+        while (idx.size() > 1) {
+            double minDiff = 1e9;
+            int b1 = -1, b2 = -1, bestId = -1;
+            Edge& kl1 = cand[idx.back()];
+            if (kl1.bad) { idx.pop_back(); continue; }
+            for (unsigned i = 0; i < idx.size() - 1; i++) {
+                Edge& kl2 = cand[idx[i]];
+                if (kl2.bad) continue;
+                unsigned p1 = kl1.other(p), p2 = kl2.other(p);
+                float ad = dirMat[(size_t)p * N + p1] - dirMat[(size_t)p * N + p2];
+                double pd = 0.5 * (distMat[(size_t)p * N + p1] + distMat[(size_t)p * N + p2]) * std::abs(std::sin(ad));
+                if (minDiff > pd) { minDiff = pd; bestId = (int)i; b1 = (int)p1; b2 = (int)p2; }
+            }
+            if (minDiff > c->line_dist_thresh) { idx.pop_back(); continue; }
+            if (ncol >= coline_cap) return -1;
+            coline_pairs[2 * ncol] = (uint32_t)b1; coline_pairs[2 * ncol + 1] = (uint32_t)b2;
+            ncol++;
+            idx.pop_back();
+            idx[bestId] = idx.back();
+            idx.pop_back();
+        }
+    }
+    coline_off[N] = ncol;
+    // compact, PPGExtractor.cpp:433-441
+    int E = 0;
+    std::vector<std::vector<unsigned>> out_conn(N);
+    for (Edge& cl : cand) {
+        if (cl.bad) continue;
+        if (E >= edge_cap) return -1;
+        edge_idx[2 * E] = cl.s; edge_idx[2 * E + 1] = cl.e; edge_score[E] = cl.lscore;
+        out_conn[cl.s].push_back(E);
+        out_conn[cl.e].push_back(E);
+        E++;
+    }
+    int k = 0;
+    for (unsigned p = 0; p < N; p++) {
+        conn_off[p] = k;
+        for (unsigned e : out_conn[p]) conn_idx[k++] = e;
+    }
+    conn_off[N] = k;
+    return E;
+}
+
+void ppgo_gen_descriptors(const ppgo_cfg* c, const float* dm, int n, const int32_t* kp_xy, float* out) {
+    const int D = c->desc_dim;
+    if (n < 10) { memset(out, 0, sizeof(float) * (size_t)n * D); return; }
+    const int W = c->width, H = c->height, w = W / 8, h = H / 8;
+    for (int i = 0; i < n; i++) {
+        // PPGExtractor.cpp:530-531: f32 / f32, then * 2. - 1. in double, stored as f32
+        float gx = (float)((double)((float)kp_xy[2 * i] / (float)W) * 2. - 1.);
+        float gy = (float)((double)((float)kp_xy[2 * i + 1] / (float)H) * 2. - 1.);
+        // ATen grid_sampler_2d, bilinear, zeros padding, align_corners = false
+        float ix = ((gx + 1.f) * w - 1.f) / 2.f, iy = ((gy + 1.f) * h - 1.f) / 2.f;
+        float fx = std::floor(ix), fy = std::floor(iy);
+        int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        float nw = ((float)x1 - ix) * ((float)y1 - iy), ne = (ix - (float)x0) * ((float)y1 - iy);
+        float sw = ((float)x1 - ix) * (iy - (float)y0), se = (ix - (float)x0) * (iy - (float)y0);
+        auto in = [&](int y, int x) { return x >= 0 && x < w && y >= 0 && y < h; };
+        float* o = out + (size_t)i * D;
+        double ss = 0.0;
+        for (int k = 0; k < D; k++) {
+            const float* p = dm + (size_t)k * h * w;
+            float v = 0.f;
+            if (in(y0, x0)) v += p[y0 * w + x0] * nw;
+            if (in(y0, x1)) v += p[y0 * w + x1] * ne;
+            if (in(y1, x0)) v += p[y1 * w + x0] * sw;
+            if (in(y1, x1)) v += p[y1 * w + x1] * se;
+            o[k] = v;
+            ss += (double)v * v;
+        }
+        float nrm = (float)std::sqrt(ss);
+        float den = nrm > 1e-12f ? nrm : 1e-12f;
+        for (int k = 0; k < D; k++) o[k] = o[k] / den;
+    }
+}
+
+float ppgo_descriptor_distance(const float* a, const float* b, int dim) {
+    float acc = 0.f;
+    for (int k = 0; k < dim; k++) {
+        float d = a[k] - b[k];
+        acc = std::fmaf(d, d, acc);
+    }
+    return std::sqrt(acc);
+}
+
+ppgo_grid* ppgo_grid_build(const ppgo_cfg* c, int n, const float* kp_pos) {
+    ppgo_grid* g = new ppgo_grid();
+    if (!c->fisheye) {
+        float cs[4][2] = {{0.f, 0.f}, {(float)c->width, 0.f}, {0.f, (float)c->height}, {(float)c->width, (float)c->height}};
+        float u[4][2];
+        for (int k = 0; k < 4; k++) undistort_pinhole(c, cs[k][0], cs[k][1], &u[k][0], &u[k][1]);
+        g->minX = (int)std::min(u[0][0], u[2][0]);
+        g->maxX = (int)std::max(u[1][0], u[3][0]);
+        g->minY = (int)std::min(u[0][1], u[1][1]);
+        g->maxY = (int)std::max(u[2][1], u[3][1]);
+    } else {
+        g->minX = 0; g->minY = 0; g->maxX = c->width; g->maxY = c->height;
+    }
+    g->invW = 64.0f / (float)(g->maxX - g->minX);
+    g->invH = 48.0f / (float)(g->maxY - g->minY);
+    g->n = n;
+    g->pos.assign(kp_pos, kp_pos + 2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        int px = (int)std::round((kp_pos[2 * i] - g->minX) * g->invW);
+        int py = (int)std::round((kp_pos[2 * i + 1] - g->minY) * g->invH);
+        if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
+        g->cell[px][py].push_back(i);
+    }
+    return g;
+}
+
+void ppgo_grid_free(ppgo_grid* g) { delete g; }
+
+int ppgo_features_in_area(const ppgo_grid* g, float x, float y, float r, int32_t* out, int cap) {
+    int cnt = 0;
+    const int minCX = std::max(0, (int)std::floor((x - g->minX - r) * g->invW));
+    if (minCX >= 64) return 0;
+    const int maxCX = std::min(63, (int)std::ceil((x - g->minX + r) * g->invW));
+    if (maxCX < 0) return 0;
+    const int minCY = std::max(0, (int)std::floor((y - g->minY - r) * g->invH));
+    if (minCY >= 48) return 0;
+    const int maxCY = std::min(47, (int)std::ceil((y - g->minY + r) * g->invH));
+    if (maxCY < 0) return 0;
+    for (int ix = minCX; ix <= maxCX; ix++)
+        for (int iy = minCY; iy <= maxCY; iy++)
+            for (int32_t id : g->cell[ix][iy]) {
+                float dx = g->pos[2 * id] - x, dy = g->pos[2 * id + 1] - y;
+                if (std::fabs(dx) < r && std::fabs(dy) < r) {
+                    if (cnt < cap) out[cnt] = id;
+                    cnt++;
+                }
+            }
+    return cnt;
+}
+
+int ppgo_search_for_initialization(const ppgo_cfg* c, float nnratio, int n1, const float* desc1,
+                                   int n2, const float* desc2, const float* pos2,
+                                   float* prev, int window, int32_t* m12) {
+    const int D = c->desc_dim;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    std::vector<int> matchedDist(n2, INT_MAX);  // vector<int> on purpose (Matcher.cpp:588)
+    std::vector<int> m21(n2, -1);
+    ppgo_grid* g = window > 0 ? ppgo_grid_build(c, n2, pos2) : nullptr;
+    std::vector<int32_t> idx(n2);
+    for (int i1 = 0; i1 < n1; i1++) {
+        int cnt;
+        if (g) cnt = ppgo_features_in_area(g, prev[2 * i1], prev[2 * i1 + 1], (float)window, idx.data(), n2);
+        else { cnt = n2; for (int k = 0; k < n2; k++) idx[k] = k; }
+        if (cnt == 0) continue;
+        const float* d1 = desc1 + (size_t)i1 * D;
+        float best = 1e6f, best2 = 1e6f;
+        int bestIdx = -1;
+        for (int k = 0; k < cnt; k++) {
+            int i2 = idx[k];
+            float dist = ppgo_descriptor_distance(d1, desc2 + (size_t)i2 * D, D);
+            if (matchedDist[i2] <= dist) continue;
+            if (dist < best) { best2 = best; best = dist; bestIdx = i2; }
+            else if (dist < best2) best2 = dist;
+        }
+        if (best <= TH_LOW) {
+            if (best < (float)best2 * nnratio) {
+                if (m21[bestIdx] >= 0) { m12[m21[bestIdx]] = -1; nmatches--; }
+                m12[i1] = bestIdx;
+                m21[bestIdx] = i1;
+                matchedDist[bestIdx] = (int)best;
+                nmatches++;
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (m12[i1] >= 0) { prev[2 * i1] = pos2[2 * m12[i1]]; prev[2 * i1 + 1] = pos2[2 * m12[i1] + 1]; }
+    if (g) ppgo_grid_free(g);
+    return nmatches;
+}
+
+int ppgo_window_nn(const float* q, int dim, const float* desc, const int32_t* cand, int ncand,
+                   const uint8_t* skip, float* best, float* second) {
+    float b = 1e6f, b2 = 1e6f;
+    int bi = -1;
+    for (int k = 0; k < ncand; k++) {
+        int id = cand[k];
+        if (skip && skip[id]) continue;
+        float d = ppgo_descriptor_distance(q, desc + (size_t)id * dim, dim);
+        if (d < b) { b2 = b; b = d; bi = id; }
+        else if (d < b2) b2 = d;
+    }
+    *best = b; *second = b2;
+    return bi;
+}
+
+int ppgo_extend_map_matches(const ppgo_cfg* c, float nnratio, float th, const ppgo_mapgraph* g,
+                            int n, const float* desc, const float* pos_un,
+                            int n_edges, const uint32_t* edge_idx,
+                            const int32_t* conn_off, const uint32_t* conn_idx,
+                            uint8_t* tracked, int32_t* frame_mp, int32_t* frame_me) {
+    (void)n_edges;
+    const int D = c->desc_dim;
+    int nmatches = 0;
+    std::vector<int> cands;
+    for (int i = 0; i < g->m; i++) {
+        if (g->bad[i] || !g->in_view[i]) continue;
+        cands.push_back(i);
+    }
+    std::sort(cands.begin(), cands.end(), [g](int a, int b) {
+        return (g->edge_off[a + 1] - g->edge_off[a]) > (g->edge_off[b + 1] - g->edge_off[b]);
+    });
+    ppgo_grid* grid = ppgo_grid_build(c, n, pos_un);
+    std::vector<int32_t> idx(n);
+    auto key_other = [&](unsigned e, unsigned pid) { return edge_idx[2 * e] == pid ? edge_idx[2 * e + 1] : edge_idx[2 * e]; };
+    for (int mp : cands) {
+        if (tracked[mp] || g->bad[mp]) continue;
+        const float* dmp = g->desc + (size_t)mp * D;
+        float best = 1e6f, best2 = 1e6f;
+        int bestIdx = -1;
+        float r = th;
+        if (g->viewcos[mp] > 0.998) r *= 2.5; else r *= 4.0;
+        int cnt = ppgo_features_in_area(grid, g->proj[2 * mp], g->proj[2 * mp + 1], r, idx.data(), n);
+        if (cnt == 0) continue;
+        for (int k = 0; k < cnt; k++) {
+            int id = idx[k];
+            if (frame_mp[id] >= 0 && g->nobs[frame_mp[id]] > 0) continue;
+            float d = ppgo_descriptor_distance(dmp, desc + (size_t)id * D, D);
+            if (d < best) { best2 = best; best = d; bestIdx = id; }
+            else if (d < best2) best2 = d;
+        }
+        if (best > TH_HIGH && best > nnratio * best2) continue;
+        frame_mp[bestIdx] = mp;
+        tracked[mp] = 1;
+        nmatches++;
+        std::deque<unsigned> seed;
+        seed.push_back((unsigned)bestIdx);
+        while (!seed.empty()) {
+            unsigned keyID = seed.front();
+            seed.pop_front();
+            const int me0 = g->edge_off[mp], nme = g->edge_off[mp + 1] - me0;  // pMP stays the first seed's point
+            const int ke0 = conn_off[keyID], nke = conn_off[keyID + 1] - ke0;
+            if (nme == 0 || nke == 0) continue;
+            std::vector<float> weight((size_t)nme * nke, 1e6f);
+            std::vector<unsigned> lx, ly;
+            for (int i = 0; i < nme; i++) {
+                if (!g->edge_ok[me0 + i] || g->edge_other[me0 + i] < 0) continue;
+                lx.push_back(i);
+            }
+            for (int j = 0; j < nke; j++) ly.push_back(j);
+            for (unsigned i : lx)
+                for (unsigned j : ly) {
+                    int mpo = g->edge_other[me0 + i];
+                    unsigned ko = key_other(conn_idx[ke0 + j], keyID);
+                    if (mpo == frame_mp[ko]) weight[(size_t)i * nke + j] = -1;
+                    else weight[(size_t)i * nke + j] =
+                             ppgo_descriptor_distance(g->desc + (size_t)mpo * D, desc + (size_t)ko * D, D);
+                }
+            while (!lx.empty() && !ly.empty()) {
+                unsigned minlx = 0, minly = 0;
+                float minW = 1e6f;
+                for (unsigned i = 0; i < lx.size(); i++)
+                    for (unsigned j = 0; j < ly.size(); j++)
+                        if (weight[(size_t)lx[i] * nke + ly[j]] < minW) {
+                            minW = weight[(size_t)lx[i] * nke + ly[j]];
+                            minlx = i; minly = j;
+                        }
+                if (minW > TH_HIGH) break;
+                unsigned mi = lx[minlx], kj = ly[minly];
+                lx.erase(lx.begin() + minlx);
+                ly.erase(ly.begin() + minly);
+                int mpo = g->edge_other[me0 + mi];
+                unsigned keyEdge = conn_idx[ke0 + kj];
+                unsigned ko = key_other(keyEdge, keyID);
+                if (mpo < 0 || g->bad[mpo] || tracked[mpo]) continue;
+                frame_mp[ko] = mpo;
+                frame_me[keyEdge] = g->edge_id[me0 + mi];
+                tracked[mpo] = 1;
+                seed.push_back(ko);
+            }
+        }
+        nmatches++;
+    }
+    ppgo_grid_free(grid);
+    return nmatches;
+}
+
+}  // extern "C"
