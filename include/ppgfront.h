@@ -1,0 +1,198 @@
+/*
+ * libppgfront — C ABI of the MI355X-native PPG-SLAM feature front-end.
+ *
+ * Drop-in boundary for the reference's feature/ (PPGExtractor) and matching/ (Matcher,
+ * DescriptorDistance) interfaces.  Plain pointers and sizes only; no C++ or torch types.
+ * Every call returns 0 on success or a negative PPG_E* code; ppg_last_error() gives the text.
+ * Nothing throws across this boundary.  A context is bound to one GPU and is not thread-safe
+ * (one context per stream / host thread), like the reference's single PPGExtractor instance
+ * (system/src/Tracking.cpp:51).
+ *
+ * Citations are relative to the reference repository root.
+ */
+#ifndef PPGFRONT_H
+#define PPGFRONT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPG_OK 0
+#define PPG_EINVAL (-1)   /* bad argument / shape */
+#define PPG_EHIP (-2)     /* HIP runtime error */
+#define PPG_EIO (-3)      /* weight blob unreadable or malformed */
+#define PPG_ENOMEM (-4)
+#define PPG_ECAP (-5)     /* a capacity given at create time was exceeded */
+
+typedef struct ppg_ctx ppg_ctx;
+
+/* Replaces the PPGExtractor constructor arguments (feature/include/PPGExtractor.h:42: camera K, D,
+ * size, fisheye flag read at feature/src/PPGExtractor.cpp:58-62; net directory :77-80) and the ten
+ * public static tunables (feature/include/PPGExtractor.h:105-114, defaults PPGExtractor.cpp:44-53). */
+typedef struct ppg_config {
+    int width, height;          /* must be multiples of 8 (PPGExtractor.cpp:163) */
+    float K[9];                 /* row-major 3x3 intrinsics */
+    float D[4];                 /* distortion; parity is pinned for D = 0 only */
+    int fisheye;
+    int device_id;
+    const char* weights_path;   /* flat fp32 blob written by tools/export_weights.py */
+    int max_batch;              /* frames per ppg_extract_batch call (>= 1) */
+    int desc_dim;               /* DESC_DIM_SIZE, 256 */
+    float junction_thresh;      /* JUNCTION_THRESH */
+    int junction_nms_radius;    /* JUNCTION_NMS_RADIUS (only 4 is built) */
+    unsigned junction_max_num;  /* JUNCTION_MAX_NUM */
+    float line_valid_thresh;    /* LINE_VALID_THRESH */
+    float line_valid_ratio;     /* LINE_VALID_RATIO */
+    float line_dist_thresh;     /* LINE_DISTTHRESH */
+    int heatmap_refine_sz;      /* HEATMAP_REFINE_SZ */
+    float line_heatmap_thresh;  /* LINE_HEATMAP_THRESH */
+    float line_inlier_rate;     /* LINE_INLIER_RATE */
+    int precision;              /* 0: fp32 operands, fp32 MFMA accumulate (parity path) */
+} ppg_config;
+
+void ppg_default_config(ppg_config* cfg, int width, int height);
+
+/* PPGExtractor::PPGExtractor (PPGExtractor.cpp:55-107): loads the weights, allocates every device
+ * and pinned buffer, warms up.  Returns NULL on failure; ppg_last_error(NULL) then holds the reason. */
+ppg_ctx* ppg_create(const ppg_config* cfg);
+void ppg_destroy(ppg_ctx* ctx);
+const char* ppg_last_error(const ppg_ctx* ctx);
+
+/* Results of PPGExtractor::run for one frame (PPGExtractor.cpp:118-147) as structure-of-arrays.
+ * Buffers are owned by the context and stay valid until the next extract call on it.
+ *   kp_xy        mvKeyPoints[i].mPos as integers (x, y)           (PPGExtractor.cpp:194)
+ *   kp_un        mPosUn (u, v)                                    (:232)
+ *   kp_out       mbOut                                            (:230-231)
+ *   desc         normDesc rows, n x desc_dim                      (:133-139)
+ *   edge_idx     mvKeyEdges[e].{startIdx,endIdx}; edge_score = lscore (:433-441)
+ *   conn_off/idx CSR of KeyPointEx::mvConnected (edge ids, reference order)
+ *   coline_*     CSR of KeyPointEx::mvColine (pairs of point ids)  (:427) */
+typedef struct ppg_frame_out {
+    int n;
+    const int32_t* kp_xy;
+    const float* kp_score;
+    const float* kp_un;
+    const uint8_t* kp_out;
+    const float* desc;
+    int n_edges;
+    const uint32_t* edge_idx;
+    const float* edge_score;
+    const int32_t* conn_off;
+    const uint32_t* conn_idx;
+    const int32_t* coline_off;
+    const uint32_t* coline_pairs;
+} ppg_frame_out;
+
+/* PPGExtractor::run (feature/include/PPGExtractor.h:50-51) for one host image (8-bit, 1 channel). */
+int ppg_extract(ppg_ctx* ctx, const uint8_t* img, int row_stride, ppg_frame_out* out);
+/* The same for n <= max_batch independent frames in one pass (multi-camera / multi-sequence mode;
+ * no counterpart in the reference, whose batch size is fixed to 1 at PPGExtractor.cpp:151). */
+int ppg_extract_batch(ppg_ctx* ctx, const uint8_t* const* imgs, int n, int row_stride, ppg_frame_out* outs);
+/* As ppg_extract_batch with the n images already resident in device memory, contiguous n*H*W bytes. */
+int ppg_extract_batch_device(ppg_ctx* ctx, const uint8_t* d_imgs, int n, ppg_frame_out* outs);
+
+/* ---- the public pipeline stages of PPGExtractor (feature/include/PPGExtractor.h:56-65), exposed so
+ * that each can be checked on its own.  They operate on the context's resident tensors for the
+ * first n frames. ---- */
+int ppg_inference(ppg_ctx* ctx, const uint8_t* imgs, int n, int on_device);  /* :149-156 (K0-K8)        */
+int ppg_detect_keypoints(ppg_ctx* ctx, int n);                               /* :158-234 (K9 + NMS)     */
+int ppg_detect_lines(ppg_ctx* ctx, int n);                                   /* :236-442 (K10 + graph)  */
+int ppg_gen_descriptors(ppg_ctx* ctx, int n);                                /* :515-538 (K11 + K12)    */
+/* Fill `outs` from the stage results (the copy-out at :130-146). */
+int ppg_collect(ppg_ctx* ctx, int n, ppg_frame_out* outs);
+
+/* Resident tensors that can be read back or overwritten for stage-wise checks.  Layouts are the
+ * device layouts: channels-last (NHWC) fp32, one frame at a time. */
+enum ppg_tensor {
+    PPG_T_FEAT = 0,      /* featureMap  [h][w][128]          (PPGExtractor.cpp:152) */
+    PPG_T_JUNC = 1,      /* junctions   [h][w][65]           (:153) */
+    PPG_T_HEAT_RAW = 2,  /* heatmap     [H][W][2]            (:154) */
+    PPG_T_DESCMAP = 3,   /* descriptors [h][w][256]          (:155) */
+    PPG_T_SCORE = 4,     /* junc_pred   [H][W]               (:162) */
+    PPG_T_HEAT = 5,      /* heatmap_score [H][W] before refineHeatMap (:242) */
+    PPG_T_HEAT_REFINED = 6 /* after refineHeatMap            (:243-256) */
+};
+size_t ppg_tensor_elems(const ppg_ctx* ctx, int which);
+int ppg_read_tensor(ppg_ctx* ctx, int which, int frame, float* dst, size_t n_elems);
+int ppg_write_tensor(ppg_ctx* ctx, int which, int frame, const float* src, size_t n_elems);
+
+/* ---- matching/ ---- */
+
+/* DescriptorDistance (feature/include/MapPoint.h:25, feature/src/MapPoint.cpp:22-29) for every pair:
+ * D[i*nB + j] = || A[i] - B[j] ||_2, rows of `dim` floats.  Host pointers.  The sum runs over
+ * d = 0..dim-1 as one fused-multiply-add chain per pair, then a correctly rounded square root. */
+int ppg_dist_matrix(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, int dim, float* D);
+
+#define PPG_MATCH_PLAIN 0  /* rows independent: first argmin, best and second-best distance only      */
+#define PPG_MATCH_INIT 1   /* Matcher::SearchForInitialization claim semantics (Matcher.cpp:591-644)  */
+
+/* Nearest-neighbour search of every row of A among candidate rows of B.
+ * cand_off/cand_idx: CSR candidate lists per A row in the order the reference would visit them
+ * (Frame::GetFeaturesInArea order, map/src/Frame.cpp:294-311); NULL = every B row, ascending.
+ * skipB (optional, nB bytes): rows of B never considered (e.g. slots already holding an observed
+ * map point, Matcher.cpp:67-69).
+ * PLAIN: match12[i] = first argmin or -1, best[i], second[i] (1e6 when absent, Matcher.cpp:62).
+ * INIT : sequential over i with the reference's claim rule; match12[i] set when
+ *        best <= th && best < second*ratio.  Returns the number of matches through *n_matches. */
+int ppg_match_nn(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, int dim,
+                 const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* skipB,
+                 float th, float ratio, int mode,
+                 int32_t* match12, float* best, float* second, int* n_matches);
+
+/* Matcher::SearchForInitialization (matching/include/Matcher.h:40, Matcher.cpp:582-651).
+ * pos2: F2.mvKeysUn[i].mPos; prev_matched (2*n1, in/out) = vbPrevMatched; window <= 0 = all pairs. */
+int ppg_search_for_initialization(ppg_ctx* ctx, float nnratio,
+                                  const float* desc1, int n1,
+                                  const float* desc2, int n2, const float* pos2,
+                                  float* prev_matched, int window, int32_t* matches12, int* n_matches);
+
+/* All-pairs SearchForInitialization between two frames of the last ppg_extract_batch call whose
+ * descriptors are still resident on the GPU (frame_a = F1, frame_b = F2); only the N1 match
+ * indices come back to the host. */
+int ppg_match_frames(ppg_ctx* ctx, int frame_a, int frame_b, float nnratio, int32_t* matches12, int* n_matches);
+
+/* Frame::GetFeaturesInArea (map/src/Frame.cpp:262-315) over the 64x48 grid built as
+ * Frame::AssignFeaturesToGrid / PosInGrid do (:138-156, :317-327) with the image bounds of
+ * GeometricCamera::InitializeImageBounds (sensors/src/GeometricCamera.cpp:26-61).  Host-side integer
+ * logic (the candidate generator of every windowed matcher). */
+typedef struct ppg_grid ppg_grid;
+ppg_grid* ppg_grid_build(const ppg_config* cfg, const float* pos, int n);
+void ppg_grid_free(ppg_grid* g);
+int ppg_features_in_area(const ppg_grid* g, float x, float y, float r, int32_t* out, int cap);
+
+/* Matcher::ExtendMapMatches (matching/include/Matcher.h:54, Matcher.cpp:203-381) on flattened state.
+ * Map points are numbered 0..m-1 in vpMapPoints order.  Per point: descriptor, mTrackProjX/Y,
+ * mTrackViewCos, mbTrackInView, isBad(), Observations(), and getEdges() as CSR entries carrying the
+ * map-edge id, the id of theOtherPt() (-1 for nullptr) and the flag !isBad() && mbValid. */
+typedef struct ppg_mapgraph {
+    int m;
+    const float* desc;
+    const float* proj;
+    const float* viewcos;
+    const uint8_t* in_view;
+    const uint8_t* bad;
+    const int32_t* nobs;
+    const int32_t* edge_off;
+    const int32_t* edge_id;
+    const int32_t* edge_other;
+    const uint8_t* edge_ok;
+} ppg_mapgraph;
+/* tracked[m]: mnTrackedbyFrame == F.mnId (in/out); frame_mp[n]: F.mvpMapPoints as ids or -1 (in/out);
+ * frame_me[n_edges]: F.mvpMapEdges as ids or -1 (in/out). *n_matches = the reference's return value. */
+int ppg_extend_map_matches(ppg_ctx* ctx, float nnratio, float th, const ppg_mapgraph* g,
+                           const float* desc, const float* pos_un, int n,
+                           const uint32_t* edge_idx, int n_edges,
+                           const int32_t* conn_off, const uint32_t* conn_idx,
+                           uint8_t* tracked, int32_t* frame_mp, int32_t* frame_me, int* n_matches);
+
+/* HIP stream the context launches on (as a void* hipStream_t) so that callers can time it with HIP
+ * events, and per-stage device time of the last extract call in milliseconds. */
+void* ppg_stream(ppg_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPGFRONT_H */

@@ -1,0 +1,270 @@
+"""ctypes binding of libppgfront.so (the MI355X-native PPG-SLAM feature front-end).
+
+This is plumbing for tests and the benchmark: it mirrors include/ppgfront.h one to one and adds
+nothing of its own.  The library has no CPU path; loading fails loudly when the .so is missing and
+`Context()` fails loudly when no gfx950 device is present.
+
+The directory name contains a hyphen, so import it with `load()` from `__graft_entry__` or
+`tests/conftest.py` (importlib by path) under the module name ``ppg_slam_amd``.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libppgfront.so")
+DEFAULT_WEIGHTS = os.path.join(_HERE, "weights", "ppg_weights.bin")
+HEADER = os.path.join(_HERE, "..", "include", "ppgfront.h")
+
+PPG_OK, PPG_EINVAL, PPG_EHIP, PPG_EIO, PPG_ENOMEM, PPG_ECAP = 0, -1, -2, -3, -4, -5
+T_FEAT, T_JUNC, T_HEAT_RAW, T_DESCMAP, T_SCORE, T_HEAT, T_HEAT_REFINED = range(7)
+MATCH_PLAIN, MATCH_INIT = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("K", C.c_float * 9), ("D", C.c_float * 4),
+                ("fisheye", C.c_int), ("device_id", C.c_int), ("weights_path", C.c_char_p), ("max_batch", C.c_int),
+                ("desc_dim", C.c_int), ("junction_thresh", C.c_float), ("junction_nms_radius", C.c_int),
+                ("junction_max_num", C.c_uint), ("line_valid_thresh", C.c_float), ("line_valid_ratio", C.c_float),
+                ("line_dist_thresh", C.c_float), ("heatmap_refine_sz", C.c_int), ("line_heatmap_thresh", C.c_float),
+                ("line_inlier_rate", C.c_float), ("precision", C.c_int)]
+
+
+class FrameOut(C.Structure):
+    _fields_ = [("n", C.c_int), ("kp_xy", C.POINTER(C.c_int32)), ("kp_score", C.POINTER(C.c_float)),
+                ("kp_un", C.POINTER(C.c_float)), ("kp_out", C.POINTER(C.c_uint8)), ("desc", C.POINTER(C.c_float)),
+                ("n_edges", C.c_int), ("edge_idx", C.POINTER(C.c_uint32)), ("edge_score", C.POINTER(C.c_float)),
+                ("conn_off", C.POINTER(C.c_int32)), ("conn_idx", C.POINTER(C.c_uint32)),
+                ("coline_off", C.POINTER(C.c_int32)), ("coline_pairs", C.POINTER(C.c_uint32))]
+
+
+class MapGraph(C.Structure):
+    _fields_ = [("m", C.c_int), ("desc", C.c_void_p), ("proj", C.c_void_p), ("viewcos", C.c_void_p),
+                ("in_view", C.c_void_p), ("bad", C.c_void_p), ("nobs", C.c_void_p), ("edge_off", C.c_void_p),
+                ("edge_id", C.c_void_p), ("edge_other", C.c_void_p), ("edge_ok", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libppgfront.so; raises if it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C ppg-slam_amd/csrc` "
+                               "(__graft_entry__.build()); the front-end has no CPU path")
+        L = C.CDLL(LIB_PATH)
+        L.ppg_create.restype = C.c_void_p
+        L.ppg_create.argtypes = [C.POINTER(Config)]
+        L.ppg_destroy.argtypes = [C.c_void_p]
+        L.ppg_last_error.restype = C.c_char_p
+        L.ppg_last_error.argtypes = [C.c_void_p]
+        L.ppg_stream.restype = C.c_void_p
+        L.ppg_stream.argtypes = [C.c_void_p]
+        L.ppg_tensor_elems.restype = C.c_size_t
+        L.ppg_tensor_elems.argtypes = [C.c_void_p, C.c_int]
+        L.ppg_grid_build.restype = C.c_void_p
+        L.ppg_grid_build.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int]
+        L.ppg_grid_free.argtypes = [C.c_void_p]
+        L.ppg_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int]
+        L.ppg_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameOut)]
+        L.ppg_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ppg_match_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_config(width, height, max_batch=1, max_num=500, weights=DEFAULT_WEIGHTS, device_id=0):
+    cfg = Config()
+    lib().ppg_default_config(C.byref(cfg), width, height)
+    cfg.max_batch = max_batch
+    cfg.junction_max_num = max_num
+    cfg.device_id = device_id
+    cfg._weights_keepalive = os.path.abspath(weights).encode()
+    cfg.weights_path = cfg._weights_keepalive
+    return cfg
+
+
+class PPGError(RuntimeError):
+    pass
+
+
+def _frame_to_dict(o):
+    n, e = o.n, o.n_edges
+    d = dict(n=n, n_edges=e)
+    d["xy"] = np.ctypeslib.as_array(o.kp_xy, (max(n, 1) * 2,))[:2 * n].reshape(n, 2).copy()
+    d["score"] = np.ctypeslib.as_array(o.kp_score, (max(n, 1),))[:n].copy()
+    d["un"] = np.ctypeslib.as_array(o.kp_un, (max(n, 1) * 2,))[:2 * n].reshape(n, 2).copy()
+    d["out"] = np.ctypeslib.as_array(o.kp_out, (max(n, 1),))[:n].copy()
+    d["desc"] = np.ctypeslib.as_array(o.desc, (max(n, 1) * 256,))[:n * 256].reshape(n, 256).copy()
+    d["edge_idx"] = (np.ctypeslib.as_array(o.edge_idx, (e * 2,)).reshape(e, 2).copy() if e else np.zeros((0, 2), np.uint32))
+    d["edge_score"] = np.ctypeslib.as_array(o.edge_score, (e,)).copy() if e else np.zeros(0, np.float32)
+    d["conn_off"] = np.ctypeslib.as_array(o.conn_off, (n + 1,)).copy()
+    nc = int(d["conn_off"][n])
+    d["conn_idx"] = np.ctypeslib.as_array(o.conn_idx, (nc,)).copy() if nc else np.zeros(0, np.uint32)
+    d["coline_off"] = np.ctypeslib.as_array(o.coline_off, (n + 1,)).copy()
+    nl = int(d["coline_off"][n])
+    d["coline_pairs"] = (np.ctypeslib.as_array(o.coline_pairs, (nl * 2,)).reshape(nl, 2).copy() if nl else np.zeros((0, 2), np.uint32))
+    return d
+
+
+class Context:
+    """Owns one ppg_ctx (one GPU, one stream)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.L = lib()
+        self.h = self.L.ppg_create(C.byref(cfg))
+        if not self.h:
+            raise PPGError("ppg_create failed: " + self.L.ppg_last_error(None).decode())
+        self.H, self.W = cfg.height, cfg.width
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ppg_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PPGError(f"libppgfront error {rc}: " + self.L.ppg_last_error(C.c_void_p(self.h)).decode())
+
+    @property
+    def stream(self):
+        return self.L.ppg_stream(C.c_void_p(self.h))
+
+    # ---- PPGExtractor::run ----
+    def extract(self, img):
+        return self.extract_batch([img])[0]
+
+    def extract_batch(self, imgs):
+        n = len(imgs)
+        arrs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        for a in arrs:
+            if a.shape != (self.H, self.W):
+                raise ValueError("image shape mismatch")
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        outs = (FrameOut * n)()
+        self._chk(self.L.ppg_extract_batch(C.c_void_p(self.h), ptrs, n, self.W, outs))
+        return [_frame_to_dict(outs[i]) for i in range(n)]
+
+    def extract_batch_device(self, dev_ptr, n, to_dict=True):
+        outs = (FrameOut * n)()
+        self._chk(self.L.ppg_extract_batch_device(C.c_void_p(self.h), C.c_void_p(dev_ptr), n, outs))
+        return [_frame_to_dict(outs[i]) for i in range(n)] if to_dict else outs
+
+    # ---- stages ----
+    def inference(self, imgs):
+        a = np.ascontiguousarray(np.stack(imgs), np.uint8)
+        self._chk(self.L.ppg_inference(C.c_void_p(self.h), _p(a), a.shape[0], 0))
+
+    def inference_device(self, dev_ptr, n):
+        self._chk(self.L.ppg_inference(C.c_void_p(self.h), C.c_void_p(dev_ptr), n, 1))
+
+    def detect_keypoints(self, n=1):
+        self._chk(self.L.ppg_detect_keypoints(C.c_void_p(self.h), n))
+
+    def detect_lines(self, n=1):
+        self._chk(self.L.ppg_detect_lines(C.c_void_p(self.h), n))
+
+    def gen_descriptors(self, n=1):
+        self._chk(self.L.ppg_gen_descriptors(C.c_void_p(self.h), n))
+
+    def collect(self, n=1):
+        outs = (FrameOut * n)()
+        self._chk(self.L.ppg_collect(C.c_void_p(self.h), n, outs))
+        return [_frame_to_dict(outs[i]) for i in range(n)]
+
+    def read_tensor(self, which, frame=0):
+        n = self.L.ppg_tensor_elems(C.c_void_p(self.h), which)
+        a = np.empty(n, np.float32)
+        self._chk(self.L.ppg_read_tensor(C.c_void_p(self.h), which, frame, _p(a), C.c_size_t(n)))
+        h, w = self.H // 8, self.W // 8
+        shape = {T_FEAT: (h, w, 128), T_JUNC: (h, w, 65), T_HEAT_RAW: (self.H, self.W, 2), T_DESCMAP: (h, w, 256),
+                 T_SCORE: (self.H, self.W), T_HEAT: (self.H, self.W), T_HEAT_REFINED: (self.H, self.W)}[which]
+        return a.reshape(shape)
+
+    def write_tensor(self, which, arr, frame=0):
+        a = np.ascontiguousarray(arr, np.float32).ravel()
+        self._chk(self.L.ppg_write_tensor(C.c_void_p(self.h), which, frame, _p(a), C.c_size_t(a.size)))
+
+    # ---- matching ----
+    def dist_matrix(self, A, B):
+        A = np.ascontiguousarray(A, np.float32)
+        B = np.ascontiguousarray(B, np.float32)
+        D = np.empty((A.shape[0], B.shape[0]), np.float32)
+        self._chk(self.L.ppg_dist_matrix(C.c_void_p(self.h), _p(A), A.shape[0], _p(B), B.shape[0], A.shape[1] if A.ndim == 2 else 256, _p(D)))
+        return D
+
+    def match_nn(self, A, B, cand_off=None, cand_idx=None, skipB=None, th=0.7, ratio=0.9, mode=MATCH_PLAIN):
+        A = np.ascontiguousarray(A, np.float32).reshape(-1, 256)
+        B = np.ascontiguousarray(B, np.float32).reshape(-1, 256)
+        nA, nB = A.shape[0], B.shape[0]
+        if cand_off is not None:
+            cand_off = np.ascontiguousarray(cand_off, np.int32)
+            cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+            if cand_idx.size == 0:
+                cand_idx = np.zeros(1, np.int32)
+        if skipB is not None:
+            skipB = np.ascontiguousarray(skipB, np.uint8)
+        m = np.full(max(nA, 1), -1, np.int32)
+        best = np.zeros(max(nA, 1), np.float32)
+        second = np.zeros(max(nA, 1), np.float32)
+        cnt = C.c_int(0)
+        self._chk(self.L.ppg_match_nn(C.c_void_p(self.h), _p(A), nA, _p(B), nB, 256, _p(cand_off), _p(cand_idx), _p(skipB),
+                                      C.c_float(th), C.c_float(ratio), mode, _p(m), _p(best), _p(second), C.byref(cnt)))
+        return m[:nA], best[:nA], second[:nA], cnt.value
+
+    def search_for_initialization(self, nnratio, desc1, desc2, pos2, prev_matched, window):
+        desc1 = np.ascontiguousarray(desc1, np.float32).reshape(-1, 256)
+        desc2 = np.ascontiguousarray(desc2, np.float32).reshape(-1, 256)
+        pos2 = np.ascontiguousarray(pos2, np.float32)
+        prev = np.array(prev_matched, np.float32, order="C", copy=True)
+        n1, n2 = desc1.shape[0], desc2.shape[0]
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        cnt = C.c_int(0)
+        self._chk(self.L.ppg_search_for_initialization(C.c_void_p(self.h), C.c_float(nnratio), _p(desc1), n1, _p(desc2), n2,
+                                                       _p(pos2), _p(prev), int(window), _p(m12), C.byref(cnt)))
+        return cnt.value, m12[:n1], prev
+
+    def match_frames(self, fa, fb, n1, nnratio=0.9):
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        cnt = C.c_int(0)
+        self._chk(self.L.ppg_match_frames(C.c_void_p(self.h), fa, fb, C.c_float(nnratio), _p(m12), C.byref(cnt)))
+        return cnt.value, m12[:n1]
+
+    def features_in_area(self, pos, x, y, r):
+        pos = np.ascontiguousarray(pos, np.float32)
+        n = pos.shape[0]
+        g = self.L.ppg_grid_build(C.byref(self.cfg), _p(pos), n)
+        out = np.zeros(max(n, 1), np.int32)
+        cnt = self.L.ppg_features_in_area(C.c_void_p(g), x, y, r, _p(out), n)
+        self.L.ppg_grid_free(C.c_void_p(g))
+        return out[:cnt].copy()
+
+    def extend_map_matches(self, nnratio, th, g, desc, pos_un, edge_idx, conn_off, conn_idx, tracked, frame_mp, frame_me):
+        keep = {k: np.ascontiguousarray(v) for k, v in g.items()}
+        mg = MapGraph()
+        mg.m = keep["desc"].shape[0]
+        for k in ("desc", "proj", "viewcos", "in_view", "bad", "nobs", "edge_off", "edge_id", "edge_other", "edge_ok"):
+            setattr(mg, k, keep[k].ctypes.data)
+        desc = np.ascontiguousarray(desc, np.float32)
+        pos_un = np.ascontiguousarray(pos_un, np.float32)
+        edge_idx = np.ascontiguousarray(edge_idx, np.uint32)
+        conn_off = np.ascontiguousarray(conn_off, np.int32)
+        conn_idx = np.ascontiguousarray(conn_idx, np.uint32)
+        tracked = np.array(tracked, np.uint8, copy=True)
+        frame_mp = np.array(frame_mp, np.int32, copy=True)
+        frame_me = np.array(frame_me, np.int32, copy=True)
+        cnt = C.c_int(0)
+        self._chk(self.L.ppg_extend_map_matches(C.c_void_p(self.h), C.c_float(nnratio), C.c_float(th), C.byref(mg), _p(desc),
+                                                _p(pos_un), desc.shape[0], _p(edge_idx), edge_idx.shape[0], _p(conn_off),
+                                                _p(conn_idx), _p(tracked), _p(frame_mp), _p(frame_me), C.byref(cnt)))
+        return cnt.value, tracked, frame_mp, frame_me

@@ -1,0 +1,1158 @@
+// Host side of libppgfront: context, weight packing, the extract pipeline, the order-dependent
+// tail of detectLines, and the matcher entry points.  C ABI in include/ppgfront.h.
+//
+// Built with -ffp-contract=off so that the host-side float formulas (line geometry) round exactly
+// as the reference's -O3 build without FMA code generation does.
+#include "../../include/ppgfront.h"
+#include "ppg_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ppg {
+hipError_t launch_dist_matrix_dev(const float* A, const int* nA_dev, int maxA, const float* B, const int* nB_dev, int maxB,
+                                  int dim, float* D, int ldd, hipStream_t s);
+}
+
+namespace {
+
+thread_local std::string g_err;  // reason of a failed ppg_create (no context to hold it)
+
+struct Tensor {
+    std::vector<uint32_t> dims;
+    std::vector<float> v;
+};
+
+struct DevConv {
+    int ks = 3, nt = 2, cin = 0, cout = 0, nblk = 0;
+    float *w = nullptr, *bias = nullptr, *alpha = nullptr, *beta = nullptr;
+};
+
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+};
+
+struct FrameHost {
+    std::vector<uint32_t> edge_idx;
+    std::vector<float> edge_score;
+    std::vector<int32_t> conn_off, coline_off;
+    std::vector<uint32_t> conn_idx, coline_pairs;
+};
+
+}  // namespace
+
+struct ppg_ctx {
+    ppg_config cfg;
+    std::string weights_path;
+    std::string err;
+    int W = 0, H = 0, w8 = 0, h8 = 0, B = 0, maxn = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> dev_allocs, host_allocs;
+    // weights
+    DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
+    float *c1a_w = nullptr, *c1a_b = nullptr, *h3_w = nullptr, *h3_b = nullptr;
+    // activations
+    uint8_t* d_img = nullptr;
+    float *a1 = nullptr, *p1 = nullptr, *a2 = nullptr, *p2 = nullptr, *a3 = nullptr, *p3 = nullptr, *a4 = nullptr,
+          *feat = nullptr, *pa_o = nullptr, *junc = nullptr, *da_o = nullptr, *descmap = nullptr, *hs0 = nullptr,
+          *hs1 = nullptr, *hs2 = nullptr, *heat_raw = nullptr, *prob = nullptr, *refined = nullptr, *score = nullptr;
+    uint8_t* state = nullptr;
+    uint32_t *resid = nullptr, *kept = nullptr;
+    unsigned long long* kept_key = nullptr;
+    int* counters = nullptr;
+    int resid_cap = 0, kept_cap = 0, cand_cap = 0, cand_fast = 0;
+    int32_t* kp_xy = nullptr;
+    float *kp_score = nullptr, *kp_un = nullptr, *desc = nullptr;
+    uint8_t* kp_out = nullptr;
+    uint32_t* cand_ij = nullptr;
+    float* cand_sc = nullptr;
+    // pinned host mirrors
+    uint8_t* h_img = nullptr;
+    int* h_counters = nullptr;
+    int32_t* h_kp_xy = nullptr;
+    float *h_kp_score = nullptr, *h_kp_un = nullptr, *h_desc = nullptr, *h_cand_sc = nullptr;
+    uint8_t* h_kp_out = nullptr;
+    uint32_t* h_cand_ij = nullptr;
+    std::vector<FrameHost> frames;
+    bool skip_score = false, skip_refine = false;
+    int last_n = 0;
+    // matcher scratch (grown on demand)
+    DBuf<float> mA, mB, mD, mBest, mSecond, mTopD;
+    DBuf<int32_t> mOff, mIdx, mMatch, mTopI;
+    DBuf<uint8_t> mSkip;
+    DBuf<uint32_t> mClaim;
+    int* mCount = nullptr;
+    int* h_mcount = nullptr;
+    int32_t* h_match = nullptr;  // pinned, maxn
+};
+
+namespace {
+
+int fail(ppg_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail((c), PPG_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+bool read_blob(const char* path, std::map<std::string, Tensor>& out, std::string& why) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { why = std::string("cannot open ") + path; return false; }
+    char magic[8];
+    uint32_t n = 0, rsv = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "PPGW0001", 8) == 0 && fread(&n, 4, 1, f) == 1 &&
+              fread(&rsv, 4, 1, f) == 1 && n < 4096;
+    struct Entry { char name[56]; uint32_t ndim; uint32_t dims[4]; uint32_t pad; uint64_t off, nbytes; };
+    static_assert(sizeof(Entry) == 96, "blob entry is 96 bytes");
+    std::vector<Entry> es(ok ? n : 0);
+    ok = ok && fread(es.data(), sizeof(Entry), n, f) == n;
+    for (size_t i = 0; ok && i < es.size(); i++) {
+        const Entry& e = es[i];
+        if (e.ndim > 4 || e.nbytes % 4 || e.nbytes > (1u << 28)) { ok = false; break; }
+        Tensor t;
+        t.dims.assign(e.dims, e.dims + e.ndim);
+        t.v.resize(e.nbytes / 4);
+        ok = fseek(f, (long)e.off, SEEK_SET) == 0 && fread(t.v.data(), 1, e.nbytes, f) == e.nbytes;
+        char nm[57];
+        memcpy(nm, e.name, 56);
+        nm[56] = 0;
+        out[nm] = std::move(t);
+    }
+    fclose(f);
+    if (!ok) why = std::string("malformed weight blob ") + path;
+    return ok;
+}
+
+template <class T>
+int dalloc(ppg_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    c->dev_allocs.push_back(q);
+    *p = (T*)q;
+    return PPG_OK;
+}
+template <class T>
+int halloc(ppg_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    HIPCHK(c, hipHostMalloc(&q, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault));
+    c->host_allocs.push_back(q);
+    *p = (T*)q;
+    return PPG_OK;
+}
+template <class T>
+int grow(ppg_ctx* c, DBuf<T>& b, size_t n) {
+    if (b.n >= n && b.p) return PPG_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.n = 0;
+    void* q = nullptr;
+    const size_t cap = std::max<size_t>(n + n / 2, 256);
+    HIPCHK(c, hipMalloc(&q, cap * sizeof(T)));
+    b.p = (T*)q;
+    b.n = cap;
+    return PPG_OK;
+}
+template <class T>
+int upload(ppg_ctx* c, T** p, const std::vector<T>& v) {
+    int rc = dalloc(c, p, v.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PPG_OK;
+}
+
+// Pack OIHW weights into the LDS image order of conv_mfma_kernel:
+//   [cout block][cin chunk][group of 8 cin][tap][half h][cout in block][4 cin]
+// with cin = chunk*KC + g*8 + h*4 + s.  `ps2` permutes couts so that a pixel-shuffle block's packed
+// cout q*Cps + c (q = 2*dy + dx) is the original channel c*4 + q
+// (pixel_shuffle: out[c][2y+dy][2x+dx] = in[c*4 + dy*2 + dx][y][x]).
+int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::string& name, int nt, bool ps2,
+              const std::string& bn_name, DevConv& dc) {
+    auto wi = t.find(name + ".weight"), bi = t.find(name + ".bias");
+    if (wi == t.end() || bi == t.end() || wi->second.dims.size() != 4)
+        return fail(c, PPG_EIO, "weight blob lacks %s", name.c_str());
+    const Tensor& w = wi->second;
+    const int cout = w.dims[0], cin = w.dims[1], ks = w.dims[2];
+    const int KC = ppg::conv_chunk(ks), NB = 32 * nt, taps = ks * ks, G = KC / 8;
+    if ((ks != 1 && ks != 3) || cin % KC) return fail(c, PPG_EIO, "%s: unsupported shape", name.c_str());
+    const int nblk = (cout + NB - 1) / NB, nchunks = cin / KC;
+    dc.ks = ks; dc.nt = nt; dc.cin = cin; dc.cout = cout; dc.nblk = nblk;
+    auto orig = [&](int cp) -> int {
+        if (cp >= cout) return -1;
+        if (!ps2) return cp;
+        const int cps = cout / 4, q = cp / cps, cc = cp % cps;
+        return cc * 4 + q;
+    };
+    std::vector<float> pk((size_t)nblk * nchunks * taps * KC * NB, 0.f);
+    for (int nb = 0; nb < nblk; nb++)
+        for (int ch = 0; ch < nchunks; ch++)
+            for (int g = 0; g < G; g++)
+                for (int tap = 0; tap < taps; tap++)
+                    for (int h = 0; h < 2; h++)
+                        for (int nn = 0; nn < NB; nn++) {
+                            const int o = orig(nb * NB + nn);
+                            if (o < 0) continue;
+                            for (int s = 0; s < 4; s++) {
+                                const int ci = ch * KC + g * 8 + h * 4 + s;
+                                const size_t dst = ((((((size_t)nb * nchunks + ch) * G + g) * taps + tap) * 2 + h) * NB + nn) * 4 + s;
+                                pk[dst] = w.v[((size_t)o * cin + ci) * taps + tap];
+                            }
+                        }
+    std::vector<float> bias((size_t)nblk * NB, 0.f), alpha, beta;
+    for (int cp = 0; cp < nblk * NB; cp++) {
+        const int o = orig(cp);
+        if (o >= 0) bias[cp] = bi->second.v[o];
+    }
+    int rc = upload(c, &dc.w, pk);
+    if (!rc) rc = upload(c, &dc.bias, bias);
+    if (rc) return rc;
+    if (!bn_name.empty()) {
+        auto g = t.find(bn_name + ".weight"), b = t.find(bn_name + ".bias"), m = t.find(bn_name + ".running_mean"),
+             v = t.find(bn_name + ".running_var");
+        if (g == t.end() || b == t.end() || m == t.end() || v == t.end())
+            return fail(c, PPG_EIO, "weight blob lacks %s", bn_name.c_str());
+        alpha.assign((size_t)nblk * NB, 1.f);
+        beta.assign((size_t)nblk * NB, 0.f);
+        for (int cp = 0; cp < nblk * NB; cp++) {
+            const int o = orig(cp);
+            if (o < 0) continue;
+            // eval-mode batch norm as ATen evaluates it: alpha = weight/sqrt(var+eps), beta = bias - mean*alpha
+            const float invstd = 1.0f / std::sqrt(v->second.v[o] + 1e-5f);
+            alpha[cp] = invstd * g->second.v[o];
+            beta[cp] = b->second.v[o] - m->second.v[o] * alpha[cp];
+        }
+        rc = upload(c, &dc.alpha, alpha);
+        if (!rc) rc = upload(c, &dc.beta, beta);
+    }
+    return rc;
+}
+
+int load_weights(ppg_ctx* c) {
+    std::map<std::string, Tensor> t;
+    std::string why;
+    if (!read_blob(c->weights_path.c_str(), t, why)) return fail(c, PPG_EIO, "%s", why.c_str());
+    int rc = 0;
+    auto mk = [&](const char* name, int nt, bool ps2, const char* bn, DevConv& dc) {
+        if (!rc) rc = make_conv(c, t, name, nt, ps2, bn, dc);
+    };
+    mk("backbone.conv1b", 2, false, "", c->c1b);
+    mk("backbone.conv2a", 2, false, "", c->c2a);
+    mk("backbone.conv2b", 2, false, "", c->c2b);
+    mk("backbone.conv3a", 2, false, "", c->c3a);
+    mk("backbone.conv3b", 2, false, "", c->c3b);
+    mk("backbone.conv4a", 2, false, "", c->c4a);
+    mk("backbone.conv4b", 2, false, "", c->c4b);
+    mk("point.convPa", 2, false, "", c->pa);
+    mk("point.convPb", 1, false, "", c->pb);
+    mk("desc.convDa", 2, false, "", c->da);
+    mk("desc.convDb", 2, false, "", c->db);
+    mk("edge.conv_block_lst.0.0", 2, true, "edge.conv_block_lst.0.1", c->h0);
+    mk("edge.conv_block_lst.1.0", 2, true, "edge.conv_block_lst.1.1", c->h1);
+    mk("edge.conv_block_lst.2.0", 1, true, "edge.conv_block_lst.2.1", c->h2);
+    if (rc) return rc;
+    auto w1 = t.find("backbone.conv1a.weight"), b1 = t.find("backbone.conv1a.bias");
+    auto w3 = t.find("edge.conv_block_lst.3.weight"), b3 = t.find("edge.conv_block_lst.3.bias");
+    if (w1 == t.end() || b1 == t.end() || w3 == t.end() || b3 == t.end() || w1->second.v.size() != 576 ||
+        w3->second.v.size() != 8)
+        return fail(c, PPG_EIO, "weight blob lacks conv1a / final heat conv");
+    std::vector<float> w1p(9 * 64);
+    for (int o = 0; o < 64; o++)
+        for (int tap = 0; tap < 9; tap++) w1p[tap * 64 + o] = w1->second.v[o * 9 + tap];
+    rc = upload(c, &c->c1a_w, w1p);
+    if (!rc) rc = upload(c, &c->c1a_b, b1->second.v);
+    if (!rc) rc = upload(c, &c->h3_w, w3->second.v);  // [2][4]
+    if (!rc) rc = upload(c, &c->h3_b, b3->second.v);
+    return rc;
+}
+
+int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, int H, int W, int mode, int relu) {
+    ppg::ConvArgs a;
+    a.in = in; a.wpk = dc.w; a.bias = dc.bias; a.alpha = dc.alpha; a.beta = dc.beta; a.out = out;
+    a.B = n; a.H = H; a.W = W; a.Cin = dc.cin; a.Cout = dc.cout;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.nblk = dc.nblk;
+    a.mode = mode; a.relu = relu;
+    HIPCHK(c, ppg::launch_conv(a, dc.ks, dc.nt, c->stream));
+    return PPG_OK;
+}
+
+ppg::NmsArgs nms_args(ppg_ctx* c, int n) {
+    ppg::NmsArgs a;
+    a.junc = c->junc; a.score = c->score; a.state = c->state; a.resid = c->resid; a.kept = c->kept;
+    a.kept_key = c->kept_key; a.counters = c->counters; a.resid_cap = c->resid_cap; a.kept_cap = c->kept_cap;
+    a.B = n; a.H = c->H; a.W = c->W; a.thresh = c->cfg.junction_thresh; a.max_num = c->maxn;
+    a.fx = c->cfg.K[0]; a.fy = c->cfg.K[4]; a.cx = c->cfg.K[2]; a.cy = c->cfg.K[5];
+    a.d0 = c->cfg.D[0]; a.d1 = c->cfg.D[1]; a.d2 = c->cfg.D[2]; a.d3 = c->cfg.D[3];
+    a.fisheye = c->cfg.fisheye;
+    a.kp_xy = c->kp_xy; a.kp_score = c->kp_score; a.kp_un = c->kp_un; a.kp_out = c->kp_out;
+    return a;
+}
+
+ppg::HeatArgs heat_args(ppg_ctx* c, int n) {
+    ppg::HeatArgs a;
+    a.ps = c->hs2; a.w = c->h3_w; a.bias = c->h3_b; a.raw = c->heat_raw; a.prob = c->prob; a.refined = c->refined;
+    a.B = n; a.H = c->H; a.W = c->W; a.refine_sz = c->cfg.heatmap_refine_sz;
+    a.valid_thresh = c->cfg.line_valid_thresh; a.valid_ratio = c->cfg.line_valid_ratio;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Order-dependent tail of detectLines (feature/src/PPGExtractor.cpp:290-441) on the candidate list
+// the GPU produced.  Candidates arrive sorted by (i, j) — the reference's loop order — each with its
+// inlier rate and mean heat.  Everything here is O(candidates x degree).
+// ---------------------------------------------------------------------------------------------
+const double kPi = 3.1415926535897932384626433832795, k2Pi = 6.283185307179586476925286766559;
+
+struct Cand {
+    uint32_t i, j;
+    float inlier, lscore_heat;
+    bool bad;
+    float lscore;
+};
+
+struct Geo {
+    const float* un;
+    float dist(uint32_t a, uint32_t b) const {  // :278-282 (symmetric by construction)
+        const uint32_t i = std::min(a, b), j = std::max(a, b);
+        const float vx = un[2 * j] - un[2 * i], vy = un[2 * j + 1] - un[2 * i + 1];
+        return std::sqrt(vx * vx + vy * vy);
+    }
+    float dir(uint32_t a, uint32_t b) const {  // :283-286
+        const uint32_t i = std::min(a, b), j = std::max(a, b);
+        float vx = un[2 * j] - un[2 * i], vy = un[2 * j + 1] - un[2 * i + 1];
+        const float d = std::sqrt(vx * vx + vy * vy);
+        vx = vx / d; vy = vy / d;
+        const float fwd = std::atan2(vy, vx);
+        if (a < b) return fwd;
+        float r = (float)(fwd - kPi);
+        if (r < -kPi) r = (float)(r + k2Pi);
+        return r;
+    }
+};
+
+void lines_tail(const ppg_config& cfg, int n, const float* un, std::vector<Cand>& cand, FrameHost& fh) {
+    Geo geo{un};
+    std::vector<std::vector<uint32_t>> conn(n);
+    std::vector<Cand> lines;  // candidateLines of the reference (survivors of the overlap test)
+    lines.reserve(cand.size());
+    auto overlap = [&](uint32_t a, uint32_t b) -> bool {  // :316-335 / :338-357
+        bool isOverlap = false;
+        for (uint32_t lid : conn[a]) {
+            Cand& old = lines[lid];
+            if (old.bad) continue;
+            const uint32_t pid_old = old.i == a ? old.j : old.i;
+            float ad = geo.dir(a, b) - geo.dir(a, pid_old);
+            if (ad < -kPi) ad = (float)(ad + k2Pi);
+            if (ad > kPi) ad = (float)(ad - k2Pi);
+            ad = std::fabs(ad);
+            if (ad > 0.2 * kPi) continue;
+            const float dNew = geo.dist(a, b), dOld = geo.dist(a, pid_old);
+            const float s = std::sin(ad);
+            if (dNew <= dOld && dNew * s < cfg.line_dist_thresh) old.bad = true;
+            if (dOld < dNew && dOld * s < cfg.line_dist_thresh) isOverlap = true;
+        }
+        return isOverlap;
+    };
+    for (Cand& cd : cand) {
+        if (overlap(cd.i, cd.j)) continue;
+        if (overlap(cd.j, cd.i)) continue;
+        cd.bad = false;
+        lines.push_back(cd);
+        const uint32_t lid = (uint32_t)lines.size() - 1;
+        conn[cd.i].push_back(lid);
+        conn[cd.j].push_back(lid);
+    }
+    for (auto& v : conn) v.clear();
+    for (uint32_t k = 0; k < lines.size(); k++) {  // :367-389
+        Cand& kl = lines[k];
+        if (kl.bad) continue;
+        if (kl.inlier < cfg.line_inlier_rate) { kl.bad = true; continue; }
+        if (kl.lscore_heat < cfg.line_heatmap_thresh) { kl.bad = true; continue; }
+        kl.lscore = kl.inlier * kl.lscore_heat;
+        conn[kl.i].push_back(k);
+        conn[kl.j].push_back(k);
+    }
+    fh.coline_off.assign(n + 1, 0);
+    fh.coline_pairs.clear();
+    for (int p = 0; p < n; p++) {  // :392-432
+        fh.coline_off[p] = (int32_t)(fh.coline_pairs.size() / 2);
+        std::vector<uint32_t> idx = conn[p];
+        while (idx.size() > 1) {
+            double minDiff = 1e9;
+            int b1 = -1, b2 = -1, bestId = -1;
+            const Cand& kl1 = lines[idx.back()];
+            if (kl1.bad) { idx.pop_back(); continue; }
+            for (uint32_t q = 0; q + 1 < idx.size(); q++) {
+                const Cand& kl2 = lines[idx[q]];
+                if (kl2.bad) continue;
+                const uint32_t p1 = kl1.i == (uint32_t)p ? kl1.j : kl1.i, p2 = kl2.i == (uint32_t)p ? kl2.j : kl2.i;
+                const float ad = geo.dir(p, p1) - geo.dir(p, p2);
+                const double pd = 0.5 * (geo.dist(p, p1) + geo.dist(p, p2)) * std::fabs(std::sin(ad));
+                if (minDiff > pd) { minDiff = pd; bestId = (int)q; b1 = (int)p1; b2 = (int)p2; }
+            }
+            if (minDiff > cfg.line_dist_thresh) { idx.pop_back(); continue; }
+            fh.coline_pairs.push_back((uint32_t)b1);
+            fh.coline_pairs.push_back((uint32_t)b2);
+            idx.pop_back();
+            idx[bestId] = idx.back();
+            idx.pop_back();
+        }
+    }
+    fh.coline_off[n] = (int32_t)(fh.coline_pairs.size() / 2);
+    fh.edge_idx.clear();
+    fh.edge_score.clear();
+    std::vector<std::vector<uint32_t>> oc(n);
+    for (const Cand& cl : lines) {  // :433-441
+        if (cl.bad) continue;
+        const uint32_t e = (uint32_t)fh.edge_score.size();
+        fh.edge_idx.push_back(cl.i);
+        fh.edge_idx.push_back(cl.j);
+        fh.edge_score.push_back(cl.lscore);
+        oc[cl.i].push_back(e);
+        oc[cl.j].push_back(e);
+    }
+    fh.conn_off.assign(n + 1, 0);
+    fh.conn_idx.clear();
+    for (int p = 0; p < n; p++) {
+        fh.conn_off[p] = (int32_t)fh.conn_idx.size();
+        for (uint32_t e : oc[p]) fh.conn_idx.push_back(e);
+    }
+    fh.conn_off[n] = (int32_t)fh.conn_idx.size();
+}
+
+size_t tensor_elems(const ppg_ctx* c, int which) {
+    const size_t hw = (size_t)c->h8 * c->w8, HW = (size_t)c->H * c->W;
+    switch (which) {
+        case PPG_T_FEAT: return hw * 128;
+        case PPG_T_JUNC: return hw * 65;
+        case PPG_T_HEAT_RAW: return HW * 2;
+        case PPG_T_DESCMAP: return hw * 256;
+        case PPG_T_SCORE: case PPG_T_HEAT: case PPG_T_HEAT_REFINED: return HW;
+        default: return 0;
+    }
+}
+float* tensor_ptr(ppg_ctx* c, int which) {
+    switch (which) {
+        case PPG_T_FEAT: return c->feat;
+        case PPG_T_JUNC: return c->junc;
+        case PPG_T_HEAT_RAW: return c->heat_raw;
+        case PPG_T_DESCMAP: return c->descmap;
+        case PPG_T_SCORE: return c->score;
+        case PPG_T_HEAT: return c->prob;
+        case PPG_T_HEAT_REFINED: return c->refined;
+        default: return nullptr;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void ppg_default_config(ppg_config* c, int width, int height) {
+    memset(c, 0, sizeof(*c));
+    c->width = width; c->height = height;
+    c->K[0] = 458.654f; c->K[4] = 457.296f; c->K[2] = width * 0.5f; c->K[5] = height * 0.5f; c->K[8] = 1.f;
+    c->max_batch = 1;
+    c->desc_dim = 256;                    // feature/src/PPGExtractor.cpp:44-53
+    c->junction_thresh = 1.0f / 128.0f;
+    c->junction_nms_radius = 4;
+    c->junction_max_num = 500;
+    c->line_valid_thresh = 1.0e-2f;
+    c->line_valid_ratio = 0.3f;
+    c->line_dist_thresh = 2.0f;
+    c->heatmap_refine_sz = 16;
+    c->line_heatmap_thresh = 0.2f;
+    c->line_inlier_rate = 0.8f;
+}
+
+const char* ppg_last_error(const ppg_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+void ppg_destroy(ppg_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->dev_allocs) (void)hipFree(p);
+    for (void* p : c->host_allocs) (void)hipHostFree(p);
+    void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
+                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p};
+    for (void* p : ms)
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(ppg_ctx* c) {
+    const ppg_config& f = c->cfg;
+    if (f.width <= 0 || f.height <= 0 || f.width % 8 || f.height % 8)
+        return fail(c, PPG_EINVAL, "image size %dx%d must be positive multiples of 8", f.width, f.height);
+    if (f.width < 16 || f.height < 16) return fail(c, PPG_EINVAL, "image too small");
+    if (f.junction_nms_radius != 4) return fail(c, PPG_EINVAL, "only JUNCTION_NMS_RADIUS = 4 is built");
+    if (f.desc_dim != 256) return fail(c, PPG_EINVAL, "only DESC_DIM_SIZE = 256 is built");
+    if (f.junction_max_num < 1 || f.junction_max_num > 4096) return fail(c, PPG_EINVAL, "junction_max_num must be 1..4096");
+    if (f.max_batch < 1 || f.max_batch > 64) return fail(c, PPG_EINVAL, "max_batch must be 1..64");
+    if (f.heatmap_refine_sz < 1 || f.heatmap_refine_sz > 16) return fail(c, PPG_EINVAL, "heatmap_refine_sz must be 1..16");
+    if (f.precision != 0) return fail(c, PPG_EINVAL, "precision %d is not built", f.precision);
+    if (!f.weights_path) return fail(c, PPG_EINVAL, "weights_path is NULL");
+    c->weights_path = f.weights_path;
+    c->cfg.weights_path = c->weights_path.c_str();
+    c->W = f.width; c->H = f.height; c->w8 = c->W / 8; c->h8 = c->H / 8; c->B = f.max_batch; c->maxn = (int)f.junction_max_num;
+    int ndev = 0;
+    HIPCHK(c, hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(c, PPG_EHIP, "no HIP device: libppgfront has no CPU path");
+    if (f.device_id < 0 || f.device_id >= ndev) return fail(c, PPG_EINVAL, "device_id %d out of range (%d devices)", f.device_id, ndev);
+    HIPCHK(c, hipSetDevice(f.device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, f.device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(c, PPG_EHIP, "device %d is %s; this library is built for gfx950 only", f.device_id, prop.gcnArchName);
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    int rc = load_weights(c);
+    if (rc) return rc;
+    const size_t B = c->B, HW = (size_t)c->H * c->W, hw = (size_t)c->h8 * c->w8;
+#define DA(ptr, n) do { rc = dalloc(c, &c->ptr, (n)); if (rc) return rc; } while (0)
+#define HA(ptr, n) do { rc = halloc(c, &c->ptr, (n)); if (rc) return rc; } while (0)
+    DA(d_img, B * HW);
+    DA(a1, B * HW * 64);
+    DA(p1, B * HW / 4 * 64);
+    DA(a2, B * HW / 4 * 64);
+    DA(p2, B * HW / 16 * 64);
+    DA(a3, B * HW / 16 * 128);
+    DA(p3, B * hw * 128);
+    DA(a4, B * hw * 128);
+    DA(feat, B * hw * 128);
+    DA(pa_o, B * hw * 256);
+    DA(junc, B * hw * 65);
+    DA(da_o, B * hw * 256);
+    DA(descmap, B * hw * 256);
+    DA(hs0, B * hw * 4 * 64);
+    DA(hs1, B * hw * 16 * 16);
+    DA(hs2, B * HW * 4);
+    DA(heat_raw, B * HW * 2);
+    DA(prob, B * HW);
+    DA(refined, B * HW);
+    DA(score, B * HW);
+    DA(state, B * HW);
+    c->resid_cap = (int)HW;
+    c->kept_cap = (int)(HW / 16 + 64);
+    c->cand_cap = std::max(1, c->maxn * (c->maxn - 1) / 2);
+    c->cand_fast = std::min(c->cand_cap, 8192);
+    DA(resid, B * c->resid_cap);
+    DA(kept, B * c->kept_cap);
+    DA(kept_key, B * c->kept_cap);
+    DA(counters, B * 8);
+    DA(kp_xy, B * c->maxn * 2);
+    DA(kp_score, B * c->maxn);
+    DA(kp_un, B * c->maxn * 2);
+    DA(kp_out, B * c->maxn);
+    DA(desc, B * c->maxn * 256);
+    DA(cand_ij, B * c->cand_cap);
+    DA(cand_sc, B * c->cand_cap * 2);
+    DA(mCount, 4);
+    HA(h_img, B * HW);
+    HA(h_counters, B * 8);
+    HA(h_kp_xy, B * c->maxn * 2);
+    HA(h_kp_score, B * c->maxn);
+    HA(h_kp_un, B * c->maxn * 2);
+    HA(h_kp_out, B * c->maxn);
+    HA(h_desc, B * c->maxn * 256);
+    HA(h_cand_ij, B * c->cand_cap);
+    HA(h_cand_sc, B * c->cand_cap * 2);
+    HA(h_mcount, 4);
+    HA(h_match, (size_t)c->maxn);
+#undef DA
+#undef HA
+    c->frames.resize(B);
+    // warm-up on an all-ones image, as the reference constructor does (PPGExtractor.cpp:100-106)
+    std::vector<uint8_t> warm(HW, 1);
+    const uint8_t* wp = warm.data();
+    ppg_frame_out tmp;
+    return ppg_extract_batch(c, &wp, 1, c->W, &tmp);
+}
+
+ppg_ctx* ppg_create(const ppg_config* cfg) {
+    if (!cfg) { fail(nullptr, PPG_EINVAL, "cfg is NULL"); return nullptr; }
+    ppg_ctx* c = new (std::nothrow) ppg_ctx();
+    if (!c) { fail(nullptr, PPG_ENOMEM, "out of host memory"); return nullptr; }
+    c->cfg = *cfg;
+    const int rc = create_impl(c);
+    if (rc != PPG_OK) {
+        g_err = c->err;
+        ppg_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void* ppg_stream(ppg_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+size_t ppg_tensor_elems(const ppg_ctx* c, int which) { return c ? tensor_elems(c, which) : 0; }
+
+int ppg_read_tensor(ppg_ctx* c, int which, int frame, float* dst, size_t n) {
+    if (!c) return PPG_EINVAL;
+    const size_t e = tensor_elems(c, which);
+    if (!e || !dst || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_read_tensor: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, tensor_ptr(c, which) + (size_t)frame * e, e * sizeof(float), hipMemcpyDeviceToHost));
+    return PPG_OK;
+}
+
+int ppg_write_tensor(ppg_ctx* c, int which, int frame, const float* src, size_t n) {
+    if (!c) return PPG_EINVAL;
+    const size_t e = tensor_elems(c, which);
+    if (!e || !src || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_write_tensor: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(tensor_ptr(c, which) + (size_t)frame * e, src, e * sizeof(float), hipMemcpyHostToDevice));
+    // an injected map replaces the one the next stage call would compute from the network outputs
+    if (which == PPG_T_SCORE) c->skip_score = true;
+    if (which == PPG_T_HEAT_REFINED) c->skip_refine = true;
+    return PPG_OK;
+}
+
+int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
+    if (!c) return PPG_EINVAL;
+    if (!imgs || n < 1 || n > c->B) return fail(c, PPG_EINVAL, "ppg_inference: n = %d outside 1..%d", n, c->B);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t HW = (size_t)c->H * c->W;
+    const uint8_t* dimg = imgs;
+    if (!on_device) {
+        if (imgs != c->h_img) memcpy(c->h_img, imgs, n * HW);
+        HIPCHK(c, hipMemcpyAsync(c->d_img, c->h_img, n * HW, hipMemcpyHostToDevice, c->stream));
+        dimg = c->d_img;
+    }
+    c->skip_score = c->skip_refine = false;
+    const int H = c->H, W = c->W;
+    ppg::Conv1aArgs a1;
+    a1.img = dimg; a1.w = c->c1a_w; a1.bias = c->c1a_b; a1.out = c->a1; a1.B = n; a1.H = H; a1.W = W;
+    HIPCHK(c, ppg::launch_conv1a(a1, c->stream));
+    int rc;
+#define RC(x) do { rc = (x); if (rc) return rc; } while (0)
+    // Backbone (net/Backbone.pt backbone.py:28-37)
+    RC(run_conv(c, c->c1b, c->a1, c->p1, n, H, W, ppg::CONV_POOL2, 1));
+    RC(run_conv(c, c->c2a, c->p1, c->a2, n, H / 2, W / 2, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, c->c2b, c->a2, c->p2, n, H / 2, W / 2, ppg::CONV_POOL2, 1));
+    RC(run_conv(c, c->c3a, c->p2, c->a3, n, H / 4, W / 4, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, c->c3b, c->a3, c->p3, n, H / 4, W / 4, ppg::CONV_POOL2, 1));
+    RC(run_conv(c, c->c4a, c->p3, c->a4, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, c->c4b, c->a4, c->feat, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    // PointHeatmap (junction_decoder.py:14-15)
+    RC(run_conv(c, c->pa, c->feat, c->pa_o, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, c->pb, c->pa_o, c->junc, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
+    // EdgeHeatmap (heatmap_decoder.py:19-22); the last 1x1 conv runs in ppg_detect_lines' first kernel
+    RC(run_conv(c, c->h0, c->feat, c->hs0, n, H / 8, W / 8, ppg::CONV_PS2, 1));
+    RC(run_conv(c, c->h1, c->hs0, c->hs1, n, H / 4, W / 4, ppg::CONV_PS2, 1));
+    RC(run_conv(c, c->h2, c->hs1, c->hs2, n, H / 2, W / 2, ppg::CONV_PS2, 1));
+    ppg::HeatArgs ha = heat_args(c, n);
+    HIPCHK(c, ppg::launch_heat_tail(ha, c->stream));
+    // Descriptor (descriptor_decoder.py:14-15)
+    RC(run_conv(c, c->da, c->feat, c->da_o, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, c->db, c->da_o, c->descmap, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
+#undef RC
+    c->last_n = n;
+    return PPG_OK;
+}
+
+int ppg_detect_keypoints(ppg_ctx* c, int n) {
+    if (!c) return PPG_EINVAL;
+    if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(int) * 8 * n, c->stream));
+    ppg::NmsArgs a = nms_args(c, n);
+    if (!c->skip_score) HIPCHK(c, ppg::launch_score_map(a, c->stream));
+    HIPCHK(c, ppg::launch_nms(a, c->stream));
+    return PPG_OK;
+}
+
+int ppg_detect_lines(ppg_ctx* c, int n) {
+    if (!c) return PPG_EINVAL;
+    if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    if (c->cfg.D[0] != 0.0f)
+        return fail(c, PPG_EINVAL, "heat-map remap for D[0] != 0 (PPGExtractor.cpp:261-262) is not built");
+    ppg::HeatArgs ha = heat_args(c, n);
+    if (!c->skip_refine) HIPCHK(c, ppg::launch_refine(ha, c->stream));
+    ppg::LineArgs la;
+    la.heat = c->refined; la.kp_un = c->kp_un; la.kp_out = c->kp_out; la.counters = c->counters;
+    la.cand_ij = c->cand_ij; la.cand_sc = c->cand_sc; la.cand_cap = c->cand_cap;
+    la.B = n; la.H = c->H; la.W = c->W; la.max_num = c->maxn;
+    la.heat_thresh = c->cfg.line_heatmap_thresh;
+    la.inv_scale = 1.0f / std::sqrt((float)(c->H * c->H + c->W * c->W));  // PPGExtractor.cpp:74
+    HIPCHK(c, ppg::launch_line_candidates(la, c->stream));
+    return PPG_OK;
+}
+
+int ppg_gen_descriptors(ppg_ctx* c, int n) {
+    if (!c) return PPG_EINVAL;
+    if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    ppg::DescArgs a;
+    a.descmap = c->descmap; a.kp_xy = c->kp_xy; a.counters = c->counters; a.desc = c->desc;
+    a.B = n; a.H = c->H; a.W = c->W; a.max_num = c->maxn;
+    HIPCHK(c, ppg::launch_desc_sample(a, c->stream));
+    return PPG_OK;
+}
+
+int ppg_collect(ppg_ctx* c, int n, ppg_frame_out* outs) {
+    if (!c) return PPG_EINVAL;
+    if (n < 1 || n > c->B || !outs) return fail(c, PPG_EINVAL, "ppg_collect: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int M = c->maxn;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->counters, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_kp_xy, c->kp_xy, sizeof(int32_t) * 2 * M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_kp_score, c->kp_score, sizeof(float) * M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_kp_un, c->kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_kp_out, c->kp_out, (size_t)M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_desc, c->desc, sizeof(float) * 256 * M * n, hipMemcpyDeviceToHost, s));
+    for (int b = 0; b < n; b++) {
+        HIPCHK(c, hipMemcpyAsync(c->h_cand_ij + (size_t)b * c->cand_cap, c->cand_ij + (size_t)b * c->cand_cap,
+                                 sizeof(uint32_t) * c->cand_fast, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_cand_sc + (size_t)b * c->cand_cap * 2, c->cand_sc + (size_t)b * c->cand_cap * 2,
+                                 sizeof(float) * 2 * c->cand_fast, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    bool more = false;
+    for (int b = 0; b < n; b++) {
+        const int* cnt = c->h_counters + b * 8;
+        if (cnt[0] > c->resid_cap || cnt[1] > c->kept_cap || cnt[2] > c->cand_cap)
+            return fail(c, PPG_ECAP, "frame %d: work list overflow (resid %d kept %d cand %d)", b, cnt[0], cnt[1], cnt[2]);
+        if (cnt[2] > c->cand_fast) {
+            more = true;
+            const size_t o = (size_t)b * c->cand_cap + c->cand_fast;
+            const size_t extra = (size_t)cnt[2] - c->cand_fast;
+            HIPCHK(c, hipMemcpyAsync(c->h_cand_ij + o, c->cand_ij + o, sizeof(uint32_t) * extra, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_cand_sc + 2 * o, c->cand_sc + 2 * o, sizeof(float) * 2 * extra, hipMemcpyDeviceToHost, s));
+        }
+    }
+    if (more) HIPCHK(c, hipStreamSynchronize(s));
+    std::vector<Cand> cand;
+    std::vector<uint32_t> order;
+    for (int b = 0; b < n; b++) {
+        const int* cnt = c->h_counters + b * 8;
+        const int N = cnt[3], nc = cnt[2];
+        FrameHost& fh = c->frames[b];
+        ppg_frame_out& o = outs[b];
+        o.n = N;
+        o.kp_xy = c->h_kp_xy + (size_t)b * M * 2;
+        o.kp_score = c->h_kp_score + (size_t)b * M;
+        o.kp_un = c->h_kp_un + (size_t)b * M * 2;
+        o.kp_out = c->h_kp_out + (size_t)b * M;
+        o.desc = c->h_desc + (size_t)b * M * 256;
+        if (N == 0) {
+            // PPGExtractor.cpp:239-240 returns before touching mvKeyEdges (stale edges of the previous
+            // frame stay in the reference's member); with no key points they index nothing, so this
+            // boundary reports an empty graph.
+            fh = FrameHost();
+            fh.conn_off.assign(1, 0);
+            fh.coline_off.assign(1, 0);
+        } else {
+            const uint32_t* ij = c->h_cand_ij + (size_t)b * c->cand_cap;
+            const float* sc = c->h_cand_sc + (size_t)b * c->cand_cap * 2;
+            order.resize(nc);
+            for (int k = 0; k < nc; k++) order[k] = k;
+            std::sort(order.begin(), order.end(), [ij](uint32_t x, uint32_t y) { return ij[x] < ij[y]; });
+            cand.resize(nc);
+            for (int k = 0; k < nc; k++) {
+                const uint32_t q = order[k];
+                cand[k] = Cand{ij[q] >> 16, ij[q] & 0xFFFFu, sc[2 * q], sc[2 * q + 1], false, 0.f};
+            }
+            lines_tail(c->cfg, N, o.kp_un, cand, fh);
+        }
+        o.n_edges = (int)fh.edge_score.size();
+        o.edge_idx = fh.edge_idx.data();
+        o.edge_score = fh.edge_score.data();
+        o.conn_off = fh.conn_off.data();
+        o.conn_idx = fh.conn_idx.data();
+        o.coline_off = fh.coline_off.data();
+        o.coline_pairs = fh.coline_pairs.data();
+    }
+    return PPG_OK;
+}
+
+static int extract_common(ppg_ctx* c, const uint8_t* imgs, int n, int on_device, ppg_frame_out* outs) {
+    int rc = ppg_inference(c, imgs, n, on_device);
+    if (!rc) rc = ppg_detect_keypoints(c, n);
+    if (!rc) rc = ppg_detect_lines(c, n);
+    if (!rc) rc = ppg_gen_descriptors(c, n);
+    if (!rc) rc = ppg_collect(c, n, outs);
+    return rc;
+}
+
+int ppg_extract_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, ppg_frame_out* outs) {
+    if (!c) return PPG_EINVAL;
+    if (!imgs || !outs || n < 1 || n > c->B || row_stride < c->W)
+        return fail(c, PPG_EINVAL, "ppg_extract_batch: bad argument (n = %d, max_batch = %d)", n, c->B);
+    const size_t HW = (size_t)c->H * c->W;
+    for (int b = 0; b < n; b++) {
+        if (!imgs[b]) return fail(c, PPG_EINVAL, "image %d is NULL", b);
+        for (int y = 0; y < c->H; y++) memcpy(c->h_img + b * HW + (size_t)y * c->W, imgs[b] + (size_t)y * row_stride, c->W);
+    }
+    return extract_common(c, c->h_img, n, 0, outs);
+}
+
+int ppg_extract(ppg_ctx* c, const uint8_t* img, int row_stride, ppg_frame_out* out) {
+    return ppg_extract_batch(c, &img, 1, row_stride, out);
+}
+
+int ppg_extract_batch_device(ppg_ctx* c, const uint8_t* d_imgs, int n, ppg_frame_out* outs) {
+    if (!c) return PPG_EINVAL;
+    if (!d_imgs || !outs || n < 1 || n > c->B) return fail(c, PPG_EINVAL, "ppg_extract_batch_device: bad argument");
+    return extract_common(c, d_imgs, n, 1, outs);
+}
+
+// ------------------------------------------------------------------------------------------
+// matching/
+// ------------------------------------------------------------------------------------------
+
+int ppg_dist_matrix(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int dim, float* D) {
+    if (!c) return PPG_EINVAL;
+    if (nA < 0 || nB < 0 || dim <= 0 || dim % 16 || (nA && !A) || (nB && !B) || (nA && nB && !D))
+        return fail(c, PPG_EINVAL, "ppg_dist_matrix: bad argument (dim must be a multiple of 16)");
+    if (nA == 0 || nB == 0) return PPG_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    int rc = grow(c, c->mA, (size_t)nA * dim);
+    if (!rc) rc = grow(c, c->mB, (size_t)nB * dim);
+    if (!rc) rc = grow(c, c->mD, (size_t)nA * nB);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->mA.p, A, sizeof(float) * nA * dim, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mB.p, B, sizeof(float) * nB * dim, hipMemcpyHostToDevice, s));
+    HIPCHK(c, ppg::launch_dist_matrix(c->mA.p, nA, c->mB.p, nB, dim, c->mD.p, nB, s));
+    HIPCHK(c, hipMemcpyAsync(D, c->mD.p, sizeof(float) * (size_t)nA * nB, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return PPG_OK;
+}
+
+int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int dim,
+                 const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* skipB,
+                 float th, float ratio, int mode, int32_t* match12, float* best, float* second, int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (nA < 0 || nB < 0 || dim <= 0 || dim % 16 || (nA && !A) || (nB && !B) || (nA && !match12) ||
+        (mode != PPG_MATCH_PLAIN && mode != PPG_MATCH_INIT) || ((cand_off == nullptr) != (cand_idx == nullptr)) || nB > 65536)
+        return fail(c, PPG_EINVAL, "ppg_match_nn: bad argument");
+    if (n_matches) *n_matches = 0;
+    if (nA == 0) return PPG_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    hipStream_t s = c->stream;
+    const bool csr = cand_off != nullptr;
+    const size_t nd = csr ? (size_t)cand_off[nA] : (size_t)nA * nB;
+    if (csr) {
+        if (cand_off[0] != 0) return fail(c, PPG_EINVAL, "cand_off[0] must be 0");
+        for (int i = 0; i < nA; i++)
+            if (cand_off[i + 1] < cand_off[i]) return fail(c, PPG_EINVAL, "cand_off must be non-decreasing");
+        for (size_t k = 0; k < nd; k++)
+            if (cand_idx[k] < 0 || cand_idx[k] >= nB) return fail(c, PPG_EINVAL, "cand_idx[%zu] out of range", k);
+    }
+    int rc = grow(c, c->mA, (size_t)nA * dim);
+    if (!rc) rc = grow(c, c->mB, (size_t)std::max(nB, 1) * dim);
+    if (!rc) rc = grow(c, c->mD, std::max<size_t>(nd, 1));
+    if (!rc) rc = grow(c, c->mMatch, nA);
+    if (!rc) rc = grow(c, c->mBest, nA);
+    if (!rc) rc = grow(c, c->mSecond, nA);
+    if (!rc) rc = grow(c, c->mTopD, (size_t)nA * 8 + 64);
+    if (!rc) rc = grow(c, c->mTopI, (size_t)nA * 8 + 64);
+    if (!rc) rc = grow(c, c->mClaim, 2048);
+    if (!rc && csr) rc = grow(c, c->mOff, (size_t)nA + 1);
+    if (!rc && csr) rc = grow(c, c->mIdx, std::max<size_t>(nd, 1));
+    if (!rc && skipB) rc = grow(c, c->mSkip, std::max(nB, 1));
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->mA.p, A, sizeof(float) * nA * dim, hipMemcpyHostToDevice, s));
+    if (nB) HIPCHK(c, hipMemcpyAsync(c->mB.p, B, sizeof(float) * nB * dim, hipMemcpyHostToDevice, s));
+    if (skipB && nB) HIPCHK(c, hipMemcpyAsync(c->mSkip.p, skipB, nB, hipMemcpyHostToDevice, s));
+    if (csr) {
+        HIPCHK(c, hipMemcpyAsync(c->mOff.p, cand_off, sizeof(int32_t) * (nA + 1), hipMemcpyHostToDevice, s));
+        if (nd) HIPCHK(c, hipMemcpyAsync(c->mIdx.p, cand_idx, sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
+        HIPCHK(c, ppg::launch_dist_csr(c->mA.p, nA, c->mB.p, dim, c->mOff.p, c->mIdx.p, c->mD.p, s));
+    } else if (nB) {
+        HIPCHK(c, ppg::launch_dist_matrix(c->mA.p, nA, c->mB.p, nB, dim, c->mD.p, nB, s));
+    }
+    ppg::MatchArgs m;
+    m.D = c->mD.p; m.ldd = csr ? 0 : nB; m.cand_off = csr ? c->mOff.p : nullptr; m.cand_idx = csr ? c->mIdx.p : nullptr;
+    m.skipB = skipB ? c->mSkip.p : nullptr; m.nA_dev = nullptr; m.nB_dev = nullptr; m.nA = nA; m.nB = nB;
+    m.th = th; m.ratio = ratio; m.topk_idx = c->mTopI.p; m.topk_dist = c->mTopD.p; m.claimed = c->mClaim.p;
+    m.match12 = c->mMatch.p; m.best = c->mBest.p; m.second = c->mSecond.p; m.n_matches = c->mCount;
+    if (!csr && nB == 0) {
+        // no candidates at all: every row is unmatched
+        for (int i = 0; i < nA; i++) { match12[i] = -1; if (best) best[i] = 1e6f; if (second) second[i] = 1e6f; }
+        return PPG_OK;
+    }
+    if (mode == PPG_MATCH_PLAIN) HIPCHK(c, ppg::launch_match_plain(m, s));
+    else HIPCHK(c, ppg::launch_match_init(m, s));
+    HIPCHK(c, hipMemcpyAsync(match12, c->mMatch.p, sizeof(int32_t) * nA, hipMemcpyDeviceToHost, s));
+    if (best) HIPCHK(c, hipMemcpyAsync(best, c->mBest.p, sizeof(float) * nA, hipMemcpyDeviceToHost, s));
+    if (second) HIPCHK(c, hipMemcpyAsync(second, c->mSecond.p, sizeof(float) * nA, hipMemcpyDeviceToHost, s));
+    if (mode == PPG_MATCH_INIT) HIPCHK(c, hipMemcpyAsync(c->h_mcount, c->mCount, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (n_matches) {
+        if (mode == PPG_MATCH_INIT) *n_matches = c->h_mcount[0];
+        else {
+            int k = 0;
+            for (int i = 0; i < nA; i++) k += match12[i] >= 0;
+            *n_matches = k;
+        }
+    }
+    return PPG_OK;
+}
+
+}  // extern "C"
+
+// ---- Frame grid (host integer logic) ----
+struct ppg_grid {
+    int minX, minY, maxX, maxY;
+    float invW, invH;
+    int n;
+    std::vector<float> pos;
+    std::vector<int32_t> cell[64][48];  // FRAME_GRID_COLS x FRAME_GRID_ROWS, sensors/include/GeometricCamera.h:79-80
+};
+
+namespace {
+void undistort_pinhole_host(const ppg_config& c, float x, float y, float* ou, float* ov) {
+    const double fx = c.K[0], fy = c.K[4], cx = c.K[2], cy = c.K[5];
+    const double k1 = c.D[0], k2 = c.D[1], p1 = c.D[2], p2 = c.D[3];
+    double xn = (x - cx) * (1.0 / fx), yn = (y - cy) * (1.0 / fy);
+    const double x0 = xn, y0 = yn;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = xn * xn + yn * yn;
+        const double icdist = 1.0 / (1.0 + ((0.0 * r2 + k2) * r2 + k1) * r2);
+        if (icdist < 0) { xn = x0; yn = y0; break; }
+        const double dX = 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn);
+        const double dY = p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn;
+        xn = (x0 - dX) * icdist;
+        yn = (y0 - dY) * icdist;
+    }
+    *ou = (float)(fx * xn + cx);
+    *ov = (float)(fy * yn + cy);
+}
+}  // namespace
+
+extern "C" {
+
+ppg_grid* ppg_grid_build(const ppg_config* cfg, const float* pos, int n) {
+    if (!cfg || n < 0 || (n && !pos)) return nullptr;
+    ppg_grid* g = new (std::nothrow) ppg_grid();
+    if (!g) return nullptr;
+    if (!cfg->fisheye) {  // sensors/src/GeometricCamera.cpp:28-47
+        const float cs[4][2] = {{0.f, 0.f}, {(float)cfg->width, 0.f}, {0.f, (float)cfg->height}, {(float)cfg->width, (float)cfg->height}};
+        float u[4][2];
+        for (int k = 0; k < 4; k++) undistort_pinhole_host(*cfg, cs[k][0], cs[k][1], &u[k][0], &u[k][1]);
+        g->minX = (int)std::min(u[0][0], u[2][0]);
+        g->maxX = (int)std::max(u[1][0], u[3][0]);
+        g->minY = (int)std::min(u[0][1], u[1][1]);
+        g->maxY = (int)std::max(u[2][1], u[3][1]);
+    } else {
+        g->minX = 0; g->minY = 0; g->maxX = cfg->width; g->maxY = cfg->height;
+    }
+    g->invW = 64.0f / (float)(g->maxX - g->minX);
+    g->invH = 48.0f / (float)(g->maxY - g->minY);
+    g->n = n;
+    g->pos.assign(pos, pos + 2 * (size_t)n);
+    for (int i = 0; i < n; i++) {  // map/src/Frame.cpp:149-155, :317-327
+        const int px = (int)std::round((pos[2 * i] - g->minX) * g->invW);
+        const int py = (int)std::round((pos[2 * i + 1] - g->minY) * g->invH);
+        if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
+        g->cell[px][py].push_back(i);
+    }
+    return g;
+}
+
+void ppg_grid_free(ppg_grid* g) { delete g; }
+
+int ppg_features_in_area(const ppg_grid* g, float x, float y, float r, int32_t* out, int cap) {
+    if (!g) return PPG_EINVAL;
+    int cnt = 0;  // map/src/Frame.cpp:262-315
+    const int minCX = std::max(0, (int)std::floor((x - g->minX - r) * g->invW));
+    if (minCX >= 64) return 0;
+    const int maxCX = std::min(63, (int)std::ceil((x - g->minX + r) * g->invW));
+    if (maxCX < 0) return 0;
+    const int minCY = std::max(0, (int)std::floor((y - g->minY - r) * g->invH));
+    if (minCY >= 48) return 0;
+    const int maxCY = std::min(47, (int)std::ceil((y - g->minY + r) * g->invH));
+    if (maxCY < 0) return 0;
+    for (int ix = minCX; ix <= maxCX; ix++)
+        for (int iy = minCY; iy <= maxCY; iy++)
+            for (int32_t id : g->cell[ix][iy]) {
+                const float dx = g->pos[2 * id] - x, dy = g->pos[2 * id + 1] - y;
+                if (std::fabs(dx) < r && std::fabs(dy) < r) {
+                    if (out && cnt < cap) out[cnt] = id;
+                    cnt++;
+                }
+            }
+    return cnt;
+}
+
+int ppg_search_for_initialization(ppg_ctx* c, float nnratio, const float* desc1, int n1, const float* desc2, int n2,
+                                  const float* pos2, float* prev, int window, int32_t* m12, int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (n1 < 0 || n2 < 0 || (n1 && (!desc1 || !m12 || !prev)) || (n2 && (!desc2 || !pos2)))
+        return fail(c, PPG_EINVAL, "ppg_search_for_initialization: bad argument");
+    int rc;
+    const float TH_LOW = 0.7f;  // matching/src/Matcher.cpp:13
+    if (window > 0) {
+        ppg_grid* g = ppg_grid_build(&c->cfg, pos2, n2);
+        if (!g) return fail(c, PPG_ENOMEM, "grid allocation failed");
+        std::vector<int32_t> off(n1 + 1, 0), idx, tmp(std::max(n2, 1));
+        for (int i = 0; i < n1; i++) {
+            const int k = ppg_features_in_area(g, prev[2 * i], prev[2 * i + 1], (float)window, tmp.data(), n2);
+            idx.insert(idx.end(), tmp.begin(), tmp.begin() + k);
+            off[i + 1] = (int32_t)idx.size();
+        }
+        ppg_grid_free(g);
+        if (idx.empty()) idx.push_back(0);
+        rc = ppg_match_nn(c, desc1, n1, desc2, n2, 256, off.data(), idx.data(), nullptr, TH_LOW, nnratio, PPG_MATCH_INIT,
+                          m12, nullptr, nullptr, n_matches);
+    } else {
+        rc = ppg_match_nn(c, desc1, n1, desc2, n2, 256, nullptr, nullptr, nullptr, TH_LOW, nnratio, PPG_MATCH_INIT, m12,
+                          nullptr, nullptr, n_matches);
+    }
+    if (rc) return rc;
+    for (int i = 0; i < n1; i++)  // Matcher.cpp:646-648
+        if (m12[i] >= 0) { prev[2 * i] = pos2[2 * m12[i]]; prev[2 * i + 1] = pos2[2 * m12[i] + 1]; }
+    return PPG_OK;
+}
+
+int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (fa < 0 || fb < 0 || fa >= c->last_n || fb >= c->last_n || !m12)
+        return fail(c, PPG_EINVAL, "ppg_match_frames: frames must be in the last extracted batch");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int M = c->maxn;
+    int rc = grow(c, c->mD, (size_t)M * M);
+    if (!rc) rc = grow(c, c->mMatch, M);
+    if (!rc) rc = grow(c, c->mBest, M);
+    if (!rc) rc = grow(c, c->mSecond, M);
+    if (!rc) rc = grow(c, c->mTopD, (size_t)M * 8 + 64);
+    if (!rc) rc = grow(c, c->mTopI, (size_t)M * 8 + 64);
+    if (!rc) rc = grow(c, c->mClaim, 2048);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const int* nA = c->counters + fa * 8 + 3;
+    const int* nB = c->counters + fb * 8 + 3;
+    HIPCHK(c, ppg::launch_dist_matrix_dev(c->desc + (size_t)fa * M * 256, nA, M, c->desc + (size_t)fb * M * 256, nB, M, 256,
+                                          c->mD.p, M, s));
+    ppg::MatchArgs m;
+    m.D = c->mD.p; m.ldd = M; m.cand_off = nullptr; m.cand_idx = nullptr; m.skipB = nullptr;
+    m.nA_dev = nA; m.nB_dev = nB; m.nA = M; m.nB = M; m.th = 0.7f; m.ratio = nnratio;
+    m.topk_idx = c->mTopI.p; m.topk_dist = c->mTopD.p; m.claimed = c->mClaim.p;
+    m.match12 = c->mMatch.p; m.best = c->mBest.p; m.second = c->mSecond.p; m.n_matches = c->mCount;
+    HIPCHK(c, ppg::launch_match_init(m, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_match, c->mMatch.p, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_mcount, c->mCount, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int n1 = c->h_counters[fa * 8 + 3];
+    memcpy(m12, c->h_match, sizeof(int32_t) * n1);
+    if (n_matches) *n_matches = c->h_mcount[0];
+    return PPG_OK;
+}
+
+int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgraph* g, const float* desc,
+                           const float* pos_un, int n, const uint32_t* edge_idx, int n_edges, const int32_t* conn_off,
+                           const uint32_t* conn_idx, uint8_t* tracked, int32_t* frame_mp, int32_t* frame_me,
+                           int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (!g || g->m < 0 || n < 0 || n_edges < 0 || (n && (!desc || !pos_un || !conn_off || !frame_mp)) ||
+        (g->m && (!g->desc || !g->proj || !g->viewcos || !g->in_view || !g->bad || !g->nobs || !g->edge_off || !tracked)))
+        return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad argument");
+    if (n_matches) *n_matches = 0;
+    const int m = g->m;
+    if (m == 0 || n == 0) return PPG_OK;
+    const float TH_HIGH = 0.8f;  // matching/src/Matcher.cpp:12
+    // every DescriptorDistance the walk can ask for is an entry of the m x n matrix: one GPU pass
+    std::vector<float> D((size_t)m * n);
+    int rc = ppg_dist_matrix(c, g->desc, m, desc, n, 256, D.data());
+    if (rc) return rc;
+    int nmatches = 0;
+    std::vector<int> cands;  // Matcher.cpp:210-222
+    for (int i = 0; i < m; i++)
+        if (!g->bad[i] && g->in_view[i]) cands.push_back(i);
+    std::sort(cands.begin(), cands.end(), [g](int a, int b) {
+        return (g->edge_off[a + 1] - g->edge_off[a]) > (g->edge_off[b + 1] - g->edge_off[b]);
+    });
+    ppg_grid* grid = ppg_grid_build(&c->cfg, pos_un, n);
+    if (!grid) return fail(c, PPG_ENOMEM, "grid allocation failed");
+    std::vector<int32_t> idx(n);
+    auto key_other = [&](uint32_t e, uint32_t pid) { return edge_idx[2 * e] == pid ? edge_idx[2 * e + 1] : edge_idx[2 * e]; };
+    for (int mp : cands) {
+        if (tracked[mp] || g->bad[mp]) continue;  // :227
+        float best = 1e6f, best2 = 1e6f;
+        int bestIdx = -1;
+        float r = th;
+        if (g->viewcos[mp] > 0.998) r *= 2.5; else r *= 4.0;  // :240-244
+        const int cnt = ppg_features_in_area(grid, g->proj[2 * mp], g->proj[2 * mp + 1], r, idx.data(), n);
+        if (cnt == 0) continue;
+        for (int k = 0; k < cnt; k++) {  // :251-270
+            const int id = idx[k];
+            if (frame_mp[id] >= 0 && g->nobs[frame_mp[id]] > 0) continue;
+            const float d = D[(size_t)mp * n + id];
+            if (d < best) { best2 = best; best = d; bestIdx = id; }
+            else if (d < best2) best2 = d;
+        }
+        if (best > TH_HIGH && best > nnratio * best2) continue;  // :276
+        frame_mp[bestIdx] = mp;
+        tracked[mp] = 1;
+        nmatches++;
+        std::deque<uint32_t> seed;  // :287-377
+        seed.push_back((uint32_t)bestIdx);
+        while (!seed.empty()) {
+            const uint32_t keyID = seed.front();
+            seed.pop_front();
+            const int me0 = g->edge_off[mp], nme = g->edge_off[mp + 1] - me0;  // the map side stays the first seed's point (:296)
+            const int ke0 = conn_off[keyID], nke = conn_off[keyID + 1] - ke0;
+            if (nme == 0 || nke == 0) continue;
+            std::vector<float> weight((size_t)nme * nke, 1e6f);
+            std::vector<uint32_t> lx, ly;
+            for (int i = 0; i < nme; i++)
+                if (g->edge_ok[me0 + i] && g->edge_other[me0 + i] >= 0) lx.push_back(i);
+            for (int j = 0; j < nke; j++) ly.push_back(j);
+            for (uint32_t i : lx)
+                for (uint32_t j : ly) {
+                    const int mpo = g->edge_other[me0 + i];
+                    const uint32_t ko = key_other(conn_idx[ke0 + j], keyID);
+                    weight[(size_t)i * nke + j] = mpo == frame_mp[ko] ? -1.f : D[(size_t)mpo * n + ko];
+                }
+            while (!lx.empty() && !ly.empty()) {
+                uint32_t minlx = 0, minly = 0;
+                float minW = 1e6f;
+                for (uint32_t i = 0; i < lx.size(); i++)
+                    for (uint32_t j = 0; j < ly.size(); j++)
+                        if (weight[(size_t)lx[i] * nke + ly[j]] < minW) { minW = weight[(size_t)lx[i] * nke + ly[j]]; minlx = i; minly = j; }
+                if (minW > TH_HIGH) break;
+                const uint32_t mi = lx[minlx], kj = ly[minly];
+                lx.erase(lx.begin() + minlx);
+                ly.erase(ly.begin() + minly);
+                const int mpo = g->edge_other[me0 + mi];
+                const uint32_t keyEdge = conn_idx[ke0 + kj];
+                const uint32_t ko = key_other(keyEdge, keyID);
+                if (mpo < 0 || g->bad[mpo] || tracked[mpo]) continue;
+                frame_mp[ko] = mpo;
+                if (frame_me) frame_me[keyEdge] = g->edge_id[me0 + mi];
+                tracked[mpo] = 1;
+                seed.push_back(ko);
+            }
+        }
+        nmatches++;  // counted twice per accepted seed (:281, :378)
+    }
+    ppg_grid_free(grid);
+    if (n_matches) *n_matches = nmatches;
+    return PPG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Launch interface between the host pipeline (ppg_front.cpp) and the gfx950 kernels (ppg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ppg {
+
+// ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ----
+enum ConvMode { CONV_PLAIN = 0, CONV_POOL2 = 1, CONV_PS2 = 2 };
+
+struct ConvArgs {
+    const float* in;     // [B][H][W][Cin] channels-last
+    const float* wpk;    // packed per (cout block, cin chunk): see pack_conv_weights()
+    const float* bias;   // [nblk*NB] (zero padded)
+    const float* alpha;  // eval-mode batch-norm scale or nullptr
+    const float* beta;   // eval-mode batch-norm shift
+    float* out;
+    int B, H, W, Cin, Cout;
+    int tiles_x, tiles_y, nblk;
+    int mode;            // ConvMode
+    int relu;
+};
+
+// ks: 1 or 3; nt: 32-wide cout tiles per wave (1 or 2)
+hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s);
+// cin chunk depth the kernel for (ks) streams through LDS; packers must use the same value
+int conv_chunk(int ks);
+
+struct Conv1aArgs {
+    const uint8_t* img;  // [B][H][W]
+    const float* w;      // [9][64]
+    const float* bias;   // [64]
+    float* out;          // [B][H][W][64]
+    int B, H, W;
+};
+hipError_t launch_conv1a(const Conv1aArgs& a, hipStream_t s);
+
+// ---- junction score map + non-maximum suppression ----
+struct NmsArgs {
+    const float* junc;    // [B][h][w][65]
+    float* score;         // [B][H][W]
+    uint8_t* state;       // [B][H*W]  0 none, 1 undecided, 2 kept, 3 suppressed
+    uint32_t* resid;      // [B][resid_cap] undecided pixels after the two parallel passes
+    uint32_t* kept;       // [B][kept_cap]
+    unsigned long long* kept_key;  // [B][kept_cap]
+    int* counters;        // [B][8]: 0 resid, 1 kept, 2 line candidates, 3 n keypoints
+    int resid_cap, kept_cap;
+    int B, H, W;
+    float thresh;
+    int max_num;
+    // camera (undistortion of the kept points)
+    float fx, fy, cx, cy, d0, d1, d2, d3;
+    int fisheye;
+    // outputs, per frame stride max_num
+    int32_t* kp_xy;       // [B][max_num][2]
+    float* kp_score;      // [B][max_num]
+    float* kp_un;         // [B][max_num][2]
+    uint8_t* kp_out;      // [B][max_num]
+};
+hipError_t launch_score_map(const NmsArgs& a, hipStream_t s);
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
+
+// ---- line heat map ----
+struct HeatArgs {
+    const float* ps;      // [B][H][W][4] output of the last pixel-shuffle block
+    const float* w;       // [2][4] 1x1 conv
+    const float* bias;    // [2]
+    float* raw;           // [B][H][W][2] (kept for checks) or nullptr
+    float* prob;          // [B][H][W]
+    float* refined;       // [B][H][W]
+    int B, H, W;
+    int refine_sz;
+    float valid_thresh, valid_ratio;
+};
+hipError_t launch_heat_tail(const HeatArgs& a, hipStream_t s);
+hipError_t launch_heat_prob_from_raw(const HeatArgs& a, hipStream_t s);
+hipError_t launch_refine(const HeatArgs& a, hipStream_t s);
+
+// ---- line candidates: state-independent part of detectLines ----
+struct LineArgs {
+    const float* heat;    // refined [B][H][W]
+    const float* kp_un;   // [B][max_num][2]
+    const uint8_t* kp_out;
+    int* counters;        // [B][8]
+    uint32_t* cand_ij;    // [B][cand_cap] (i << 16 | j)
+    float* cand_sc;       // [B][cand_cap][2] inlier rate, mean bilinear heat
+    int cand_cap;
+    int B, H, W, max_num;
+    float heat_thresh;
+    float inv_scale;
+};
+hipError_t launch_line_candidates(const LineArgs& a, hipStream_t s);
+
+// ---- descriptor sampling + L2 normalisation ----
+struct DescArgs {
+    const float* descmap;  // [B][h][w][256]
+    const int32_t* kp_xy;
+    const int* counters;
+    float* desc;           // [B][max_num][256]
+    int B, H, W, max_num;
+};
+hipError_t launch_desc_sample(const DescArgs& a, hipStream_t s);
+
+// ---- descriptor matching ----
+// D[i*ldd + j] = ||A[i] - B[j]||, dim 256 (multiple of 16)
+hipError_t launch_dist_matrix(const float* A, int nA, const float* B, int nB, int dim, float* D, int ldd, hipStream_t s);
+// distances for CSR candidate lists: Dc[cand_off[i] + k] = ||A[i] - B[cand_idx[cand_off[i]+k]]||
+hipError_t launch_dist_csr(const float* A, int nA, const float* B, int dim, const int32_t* cand_off,
+                           const int32_t* cand_idx, float* Dc, hipStream_t s);
+
+struct MatchArgs {
+    const float* D;            // dense: [nA][ldd]; CSR: flat
+    int ldd;                   // dense row stride (0 => CSR)
+    const int32_t* cand_off;   // CSR (may be nullptr when dense)
+    const int32_t* cand_idx;
+    const uint8_t* skipB;      // optional
+    const int* nA_dev;         // optional device-resident row count (overrides nA when non-null)
+    const int* nB_dev;
+    int nA, nB;
+    float th, ratio;
+    int32_t* topk_idx;         // [nA][8] work
+    float* topk_dist;          // [nA][8] work
+    uint32_t* claimed;         // [(nB+31)/32] work
+    int32_t* match12;          // [nA]
+    float* best;               // [nA]
+    float* second;             // [nA]
+    int* n_matches;            // device int
+};
+hipError_t launch_match_plain(const MatchArgs& a, hipStream_t s);
+hipError_t launch_match_init(const MatchArgs& a, hipStream_t s);
+
+}  // namespace ppg

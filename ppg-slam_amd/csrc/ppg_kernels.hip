@@ -1,0 +1,1085 @@
+// gfx950 (MI355X, CDNA4) kernels of the PPG front-end.  Wave = 64 lanes everywhere.
+//
+// Built with -ffp-contract=off: every float expression below rounds exactly as written, and fused
+// multiply-adds appear only where fmaf()/MFMA is spelled out.  That is what lets the integer outputs
+// (keypoints, line candidates, match indices) agree bit for bit with a strict-IEEE CPU evaluation of
+// the reference's formulas.
+#include "ppg_kernels.h"
+
+#include <math.h>
+
+namespace ppg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =====================================================================================
+// Convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32: each product is one fmaf into
+// the accumulator, so the result is a k-ordered fmaf chain).
+//
+// Reference op: every `torch._convolution` of net/*.pt (3x3 stride 1 pad 1, or 1x1), followed by
+// the ReLU / max_pool2d(2,2) / batch_norm+ReLU+pixel_shuffle(2) that the graphs apply next
+// (net/Backbone.pt code/__torch__/model/nets/backbone.py:28-37,
+//  net/EdgeHeatmap.pt .../heatmap_decoder.py:19-22).
+//
+// Work-group = 4 waves, output tile 8 rows x 32 columns x NB couts (NB = 32*NT).
+// Wave w owns rows 2w, 2w+1 (two 32-pixel M tiles) x NT 32-cout N tiles.
+//   A operand (lane l): pixel x = l&31 of the row, cin = 4*(l>>5)+s for the s-th MFMA of a group
+//   B operand (lane l): cout = l&31,               same cin
+//   D: lane holds cout l&31; register r holds pixel x = (r&3) + 8*(r>>2) + 4*(l>>5)
+// so the 2x2 max-pool needs no cross-lane traffic: vertical = the two M tiles, horizontal = register pairs.
+// Input is streamed through LDS in chunks of KC input channels (pixel stride KC+4 floats keeps the
+// 16-byte fragment reads of a 16-lane group on distinct banks); weights arrive pre-packed in
+// exactly the LDS image order.  Two LDS buffers: the next chunk is fetched into registers before the
+// MFMAs of the current one and written to the other buffer after them, one barrier per chunk.
+// =====================================================================================
+constexpr int TH = 8, TW = 32;
+
+template <int KS, int NT, int KC>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int IH = TH + KS - 1, IW = TW + KS - 1, IN_PIX = IH * IW;
+    constexpr int PSTR = KC + 4;
+    constexpr int NB = 32 * NT;
+    constexpr int TAPS = KS * KS;
+    constexpr int IN_FLOATS = IN_PIX * PSTR;
+    constexpr int W_FLOATS = TAPS * KC * NB;
+    constexpr int QPP = KC / 4;
+    constexpr int IN_ITEMS = IN_PIX * QPP;
+    constexpr int IN_PER_T = (IN_ITEMS + 255) / 256;
+    constexpr int W_ITEMS = W_FLOATS / 4;
+    constexpr int W_PER_T = (W_ITEMS + 255) / 256;
+    constexpr int BUF = IN_FLOATS + W_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int bx = blockIdx.x;
+    const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, b = bx / (a.tiles_x * a.tiles_y);
+    const int nb = blockIdx.y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int nchunks = a.Cin / KC;
+
+    long gofs[IN_PER_T];
+    int lofs[IN_PER_T];
+#pragma unroll
+    for (int k = 0; k < IN_PER_T; k++) {
+        const int item = tid + 256 * k;
+        gofs[k] = -1;
+        lofs[k] = -1;
+        if (item < IN_ITEMS) {
+            const int pix = item / QPP, q = item % QPP;
+            const int py = pix / IW, px = pix % IW;
+            const int gy = y0 + py - PAD, gx = x0 + px - PAD;
+            lofs[k] = pix * PSTR + q * 4;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                gofs[k] = ((long)(b * a.H + gy) * a.W + gx) * a.Cin + q * 4;
+        }
+    }
+    const float* wsrc = a.wpk + (size_t)nb * nchunks * W_FLOATS;
+
+    f32x4 vin[IN_PER_T], vw[W_PER_T];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < IN_PER_T; k++) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            vin[k] = gofs[k] >= 0 ? *(const f32x4*)(a.in + gofs[k] + c * KC) : z;
+        }
+#pragma unroll
+        for (int k = 0; k < W_PER_T; k++) {
+            const int item = tid + 256 * k;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            vw[k] = item < W_ITEMS ? *(const f32x4*)(wsrc + (size_t)c * W_FLOATS + item * 4) : z;
+        }
+    };
+    auto stash = [&](int buf) {
+        float* ins = smem + buf * BUF;
+        float* ws = ins + IN_FLOATS;
+#pragma unroll
+        for (int k = 0; k < IN_PER_T; k++)
+            if (lofs[k] >= 0) *(f32x4*)(ins + lofs[k]) = vin[k];
+#pragma unroll
+        for (int k = 0; k < W_PER_T; k++) {
+            const int item = tid + 256 * k;
+            if (item < W_ITEMS) *(f32x4*)(ws + item * 4) = vw[k];
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch(c + 1);
+        const float* ins = smem + buf * BUF;
+        const float* ws = ins + IN_FLOATS;
+#pragma unroll
+        for (int g = 0; g < KC / 8; g++) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; tap++) {
+                const int ky = tap / KS, kx = tap % KS;
+                f32x4 av[2], bv[NT];
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+                    av[m] = *(const f32x4*)(ins + ((2 * wave + m + ky) * IW + (li + kx)) * PSTR + g * 8 + lh * 4);
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+                    bv[n] = *(const f32x4*)(ws + (((g * TAPS + tap) * 2 + lh) * NB + n * 32 + li) * 4);
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+#pragma unroll
+                        for (int n = 0; n < NT; n++)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store ----
+    const int yrow = y0 + 2 * wave;
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        const int co = nb * NB + n * 32 + li;
+        const float bias = a.bias[co];
+        float al = 1.f, be = 0.f;
+        const bool bn = a.alpha != nullptr;
+        if (bn) { al = a.alpha[co]; be = a.beta[co]; }
+        if (co >= a.Cout) continue;
+        if (a.mode == CONV_POOL2) {
+            const int Hp = a.H / 2, Wp = a.W / 2;
+            if (yrow + 1 < a.H) {
+#pragma unroll
+                for (int rp = 0; rp < 8; rp++) {
+                    const int r0 = 2 * rp;
+                    const int x = x0 + (r0 & 3) + 8 * (r0 >> 2) + 4 * lh;
+                    if (x + 1 < a.W) {
+                        float v = fmaxf(fmaxf(acc[0][n][r0], acc[0][n][r0 + 1]), fmaxf(acc[1][n][r0], acc[1][n][r0 + 1]));
+                        v = v + bias;
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        a.out[((size_t)(b * Hp + (yrow >> 1)) * Wp + (x >> 1)) * a.Cout + co] = v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int y = yrow + m;
+                if (y >= a.H) continue;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (x >= a.W) continue;
+                    float v = acc[m][n][r] + bias;
+                    if (bn) v = v * al + be;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.mode == CONV_PLAIN) {
+                        a.out[((size_t)(b * a.H + y) * a.W + x) * a.Cout + co] = v;
+                    } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx
+                        const int Cps = a.Cout >> 2;
+                        const int q = co / Cps, cc = co - q * Cps;
+                        const int Y = 2 * y + (q >> 1), X = 2 * x + (q & 1);
+                        a.out[((size_t)(b * 2 * a.H + Y) * (2 * a.W) + X) * Cps + cc] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
+
+hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
+    dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
+    if (ks == 3 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8>), grid, block, 0, s, a);
+    else if (ks == 3 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8>), grid, block, 0, s, a);
+    else if (ks == 1 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 16>), grid, block, 0, s, a);
+    else if (ks == 1 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 16>), grid, block, 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// conv1a: uint8 image -> /255 (true division, feature/src/PPGExtractor.cpp:151) -> 3x3 conv 1->64
+// + ReLU (backbone.py:28).  K = 9 is too shallow for MFMA; this is a store-bound VALU kernel.
+// 16 threads per pixel, 4 couts each, so one wave store covers 1 KiB of contiguous NHWC output.
+// =====================================================================================
+__global__ __launch_bounds__(256) void conv1a_kernel(Conv1aArgs a) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long pix = gid >> 4;
+    const int cg = (int)(gid & 15);
+    const long total = (long)a.B * a.H * a.W;
+    if (pix >= total) return;
+    const int x = (int)(pix % a.W), y = (int)((pix / a.W) % a.H);
+    const int b = (int)(pix / ((long)a.W * a.H));
+    const uint8_t* im = a.img + (size_t)b * a.H * a.W;
+    f32x4 acc = *(const f32x4*)(a.bias + cg * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            float v = 0.f;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = lut[im[(size_t)yy * a.W + xx]];
+            const f32x4 w = *(const f32x4*)(a.w + (ky * 3 + kx) * 64 + cg * 4);
+            acc[0] = fmaf(v, w[0], acc[0]);
+            acc[1] = fmaf(v, w[1], acc[1]);
+            acc[2] = fmaf(v, w[2], acc[2]);
+            acc[3] = fmaf(v, w[3], acc[3]);
+        }
+    acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f);
+    acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f);
+    *(f32x4*)(a.out + (size_t)pix * 64 + cg * 4) = acc;
+}
+
+hipError_t launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
+    const long threads = (long)a.B * a.H * a.W * 16;
+    hipLaunchKernelGGL(conv1a_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Wave helpers
+// =====================================================================================
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// =====================================================================================
+// Score map: softmax over the 65 junction channels, drop the dustbin, depth-to-space x8
+// (feature/src/PPGExtractor.cpp:161-162).  One wave per 8x8 cell, lane = channel.
+// =====================================================================================
+__global__ __launch_bounds__(256) void score_map_kernel(NmsArgs a) {
+    const int h = a.H / 8, w = a.W / 8;
+    const long cell = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (cell >= (long)a.B * h * w) return;
+    const int cx = (int)(cell % w), cy = (int)((cell / w) % h), b = (int)(cell / ((long)w * h));
+    const float* p = a.junc + (size_t)cell * 65;
+    const float v = p[lane], dust = p[64];
+    const float m = wave_max(fmaxf(v, dust));
+    const float e = expf(v - m), ed = expf(dust - m);
+    const float s = wave_sum(e) + ed;
+    a.score[((size_t)b * a.H + cy * 8 + (lane >> 3)) * a.W + cx * 8 + (lane & 7)] = e / s;
+}
+
+hipError_t launch_score_map(const NmsArgs& a, hipStream_t s) {
+    const long cells = (long)a.B * (a.H / 8) * (a.W / 8);
+    hipLaunchKernelGGL(score_map_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Greedy radius-4 NMS of feature/src/PPGExtractor.cpp:166-206, reformulated so that it runs in
+// parallel yet returns exactly the sequential result.
+//
+// The reference visits candidates (score >= thresh, >= 4 px from the border) in descending score and
+// keeps one iff no already-kept candidate lies within +-4 px.  With the total order
+//     p beats q  <=>  score_p > score_q  or  (score_p == score_q and index_p < index_q)
+// (index = y*W + x; the reference's std::sort leaves ties unspecified) that is the unique fixed
+// point of:  kept(p) <=> no kept q in the window beats p.  Passes:
+//   A  (tiles) local maxima of the order are kept; every other candidate is undecided
+//   B  (tiles) undecided next to a kept pixel -> suppressed; the rest go to a residual list
+//   C  (one work-group per frame) iterate on the residual list until nothing is undecided
+//   D  (one work-group per frame) rank the kept pixels by the same order, emit the first max_num
+//      (the reference's early break at JUNCTION_MAX_NUM, :195-196), undistort them (:212-233).
+// =====================================================================================
+constexpr int NT_TILE = 32, NR = 4, NT_LD = NT_TILE + 2 * NR;  // 40
+
+__device__ inline bool beats(float sq, int dy, int dx, float sp) {
+    return sq > sp || (sq == sp && (dy < 0 || (dy == 0 && dx < 0)));
+}
+
+__global__ __launch_bounds__(256) void nms_local_max_kernel(NmsArgs a) {
+    __shared__ float sh[NT_LD][NT_LD + 1];
+    const int b = blockIdx.z, ox = blockIdx.x * NT_TILE, oy = blockIdx.y * NT_TILE;
+    const float* sc = a.score + (size_t)b * a.H * a.W;
+    for (int i = threadIdx.x; i < NT_LD * NT_LD; i += 256) {
+        const int ly = i / NT_LD, lx = i % NT_LD;
+        const int gy = oy + ly - NR, gx = ox + lx - NR;
+        float v = -1.f;
+        if (gx >= NR && gx <= a.W - NR - 1 && gy >= NR && gy <= a.H - NR - 1) {
+            const float s = sc[(size_t)gy * a.W + gx];
+            if (!(s < a.thresh)) v = s;
+        }
+        sh[ly][lx] = v;
+    }
+    __syncthreads();
+    uint8_t* st = a.state + (size_t)b * a.H * a.W;
+    for (int i = threadIdx.x; i < NT_TILE * NT_TILE; i += 256) {
+        const int ly = i / NT_TILE, lx = i % NT_TILE;
+        const int gy = oy + ly, gx = ox + lx;
+        if (gy >= a.H || gx >= a.W) continue;
+        const float sp = sh[ly + NR][lx + NR];
+        uint8_t r = 0;
+        if (sp >= 0.f) {
+            bool beaten = false;
+            for (int dy = -NR; dy <= NR && !beaten; dy++)
+                for (int dx = -NR; dx <= NR; dx++) {
+                    const float sq = sh[ly + NR + dy][lx + NR + dx];
+                    if (sq >= 0.f && (dy | dx) != 0 && beats(sq, dy, dx, sp)) { beaten = true; break; }
+                }
+            r = beaten ? 1 : 2;
+        }
+        st[(size_t)gy * a.W + gx] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_suppress_kernel(NmsArgs a) {
+    __shared__ uint8_t sh[NT_LD][NT_LD + 8];
+    const int b = blockIdx.z, ox = blockIdx.x * NT_TILE, oy = blockIdx.y * NT_TILE;
+    uint8_t* st = a.state + (size_t)b * a.H * a.W;
+    for (int i = threadIdx.x; i < NT_LD * NT_LD; i += 256) {
+        const int ly = i / NT_LD, lx = i % NT_LD;
+        const int gy = oy + ly - NR, gx = ox + lx - NR;
+        uint8_t v = 0;
+        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) v = st[(size_t)gy * a.W + gx];
+        sh[ly][lx] = v;
+    }
+    __syncthreads();
+    int* cnt = a.counters + b * 8;
+    for (int i = threadIdx.x; i < NT_TILE * NT_TILE; i += 256) {
+        const int ly = i / NT_TILE, lx = i % NT_TILE;
+        const int gy = oy + ly, gx = ox + lx;
+        if (gy >= a.H || gx >= a.W) continue;
+        const uint8_t s0 = sh[ly + NR][lx + NR];
+        const uint32_t idx = (uint32_t)(gy * a.W + gx);
+        if (s0 == 2) {
+            const int k = atomicAdd(&cnt[1], 1);
+            if (k < a.kept_cap) a.kept[(size_t)b * a.kept_cap + k] = idx;
+        } else if (s0 == 1) {
+            bool sup = false;
+            for (int dy = -NR; dy <= NR && !sup; dy++)
+                for (int dx = -NR; dx <= NR; dx++)
+                    if (sh[ly + NR + dy][lx + NR + dx] == 2) { sup = true; break; }
+            if (sup) {
+                // only this thread writes this pixel; neighbours test for == 2 only, which never changes here
+                st[idx] = 3;
+            } else {
+                const int k = atomicAdd(&cnt[0], 1);
+                if (k < a.resid_cap) a.resid[(size_t)b * a.resid_cap + k] = idx;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void nms_resolve_kernel(NmsArgs a) {
+    const int b = blockIdx.x;
+    uint8_t* st = a.state + (size_t)b * a.H * a.W;
+    const float* sc = a.score + (size_t)b * a.H * a.W;
+    int* cnt = a.counters + b * 8;
+    const int nres = min(cnt[0], a.resid_cap);
+    const uint32_t* resid = a.resid + (size_t)b * a.resid_cap;
+    // Every round decides at least the best undecided pixel, so nres + 1 rounds always suffice.
+    for (int round = 0; round <= nres; round++) {
+        int remaining = 0;
+        for (int k = threadIdx.x; k < nres; k += 1024) {
+            const int p = (int)resid[k];
+            if (st[p] != 1) continue;
+            const int py = p / a.W, px = p % a.W;
+            const float sp = sc[p];
+            bool sup = false, blocked = false;
+            for (int dy = -NR; dy <= NR && !sup; dy++) {
+                const int qy = py + dy;
+                if (qy < 0 || qy >= a.H) continue;
+                for (int dx = -NR; dx <= NR; dx++) {
+                    const int qx = px + dx;
+                    if (qx < 0 || qx >= a.W || (dy | dx) == 0) continue;
+                    const uint8_t sq = st[qy * a.W + qx];
+                    if (sq == 2) { sup = true; break; }
+                    if (sq == 1 && beats(sc[qy * a.W + qx], dy, dx, sp)) blocked = true;
+                }
+            }
+            if (sup) st[p] = 3;
+            else if (!blocked) {
+                st[p] = 2;
+                const int kk = atomicAdd(&cnt[1], 1);
+                if (kk < a.kept_cap) a.kept[(size_t)b * a.kept_cap + kk] = (uint32_t)p;
+            } else remaining++;
+        }
+        // barrier + work-group-wide visibility of the state bytes written above
+        if (__syncthreads_count(remaining) == 0) break;
+    }
+}
+
+// cv::undistortPoints(src, dst, K, D, noArray(), P = K) for a 4-coefficient pinhole model: five
+// fixed-point iterations in double (OpenCV's published algorithm; identity for D = 0).
+__device__ inline void undistort_pinhole_dev(const NmsArgs& a, float x, float y, float* ou, float* ov) {
+    const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+    const double k1 = a.d0, k2 = a.d1, p1 = a.d2, p2 = a.d3;
+    double xn = (x - cx) * (1.0 / fx), yn = (y - cy) * (1.0 / fy);
+    const double x0 = xn, y0 = yn;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = xn * xn + yn * yn;
+        const double icdist = 1.0 / (1.0 + ((0.0 * r2 + k2) * r2 + k1) * r2);
+        if (icdist < 0) { xn = x0; yn = y0; break; }
+        const double dX = 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn);
+        const double dY = p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn;
+        xn = (x0 - dX) * icdist;
+        yn = (y0 - dY) * icdist;
+    }
+    *ou = (float)(fx * xn + cx);
+    *ov = (float)(fy * yn + cy);
+}
+
+// cv::fisheye::undistortPoints(src, dst, K, D, noArray(), P = K): Newton iteration on theta.
+__device__ inline void undistort_fisheye_dev(const NmsArgs& a, float x, float y, float* ou, float* ov) {
+    const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+    const double k0 = a.d0, k1 = a.d1, k2 = a.d2, k3 = a.d3;
+    const double kPi = 3.1415926535897932384626433832795;
+    const double px = (x - cx) / fx, py = (y - cy) / fy;
+    double theta_d = sqrt(px * px + py * py);
+    theta_d = fmin(fmax(-kPi / 2., theta_d), kPi / 2.);
+    double scale = 1.0;
+    if (theta_d > 1e-8) {
+        double theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+            const double k0t2 = k0 * t2, k1t4 = k1 * t4, k2t6 = k2 * t6, k3t8 = k3 * t8;
+            const double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) /
+                               (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+            theta = theta - fix;
+            if (fabs(fix) < 1e-8) break;
+        }
+        scale = tan(theta) / theta_d;
+    }
+    *ou = (float)(fx * (px * scale) + cx);
+    *ov = (float)(fy * (py * scale) + cy);
+}
+
+__global__ __launch_bounds__(1024) void nms_emit_kernel(NmsArgs a) {
+    const int b = blockIdx.x;
+    int* cnt = a.counters + b * 8;
+    const int S = min(cnt[1], a.kept_cap);
+    const float* sc = a.score + (size_t)b * a.H * a.W;
+    const uint32_t* kept = a.kept + (size_t)b * a.kept_cap;
+    unsigned long long* key = a.kept_key + (size_t)b * a.kept_cap;
+    // key: larger = better.  Scores are positive floats, so their bit patterns order like the values.
+    for (int k = threadIdx.x; k < S; k += 1024) {
+        const uint32_t p = kept[k];
+        key[k] = ((unsigned long long)__float_as_uint(sc[p]) << 32) | (unsigned long long)(0xFFFFFFFFu - p);
+    }
+    __syncthreads();
+    const int n = min(S, a.max_num);
+    for (int k = threadIdx.x; k < S; k += 1024) {
+        const unsigned long long mine = key[k];
+        int rank = 0;
+        for (int j = 0; j < S; j++) rank += key[j] > mine;
+        if (rank < n) {
+            const uint32_t p = kept[k];
+            const int x = (int)(p % (uint32_t)a.W), y = (int)(p / (uint32_t)a.W);
+            const size_t o = (size_t)b * a.max_num + rank;
+            a.kp_xy[2 * o] = x;
+            a.kp_xy[2 * o + 1] = y;
+            a.kp_score[o] = sc[p];
+            float u, v;
+            if (a.fisheye) undistort_fisheye_dev(a, (float)x, (float)y, &u, &v);
+            else undistort_pinhole_dev(a, (float)x, (float)y, &u, &v);
+            a.kp_un[2 * o] = u;
+            a.kp_un[2 * o + 1] = v;
+            a.kp_out[o] = !(u >= 1 && u < a.W - 1 && v >= 1 && v < a.H - 1);
+        }
+    }
+    if (threadIdx.x == 0) cnt[3] = n;
+}
+
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
+    dim3 grid((a.W + NT_TILE - 1) / NT_TILE, (a.H + NT_TILE - 1) / NT_TILE, a.B);
+    hipLaunchKernelGGL(nms_local_max_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nms_suppress_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nms_resolve_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Line heat map: 1x1 conv 4->2 (net/EdgeHeatmap.pt .../heatmap_decoder.py:22), softmax over the two
+// channels, channel 1 (feature/src/PPGExtractor.cpp:242).
+// =====================================================================================
+__device__ inline float softmax2_ch1(float h0, float h1) {
+    const float m = fmaxf(h0, h1);
+    const float e0 = expf(h0 - m), e1 = expf(h1 - m);
+    return e1 / (e0 + e1);
+}
+
+__global__ __launch_bounds__(256) void heat_tail_kernel(HeatArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.B * a.H * a.W;
+    if (i >= total) return;
+    const f32x4 v = *(const f32x4*)(a.ps + (size_t)i * 4);
+    float h0 = a.bias[0], h1 = a.bias[1];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        h0 = fmaf(v[c], a.w[c], h0);
+        h1 = fmaf(v[c], a.w[4 + c], h1);
+    }
+    if (a.raw) { a.raw[2 * i] = h0; a.raw[2 * i + 1] = h1; }
+    a.prob[i] = softmax2_ch1(h0, h1);
+}
+
+__global__ __launch_bounds__(256) void heat_prob_kernel(HeatArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.B * a.H * a.W;
+    if (i >= total) return;
+    a.prob[i] = softmax2_ch1(a.raw[2 * i], a.raw[2 * i + 1]);
+}
+
+hipError_t launch_heat_tail(const HeatArgs& a, hipStream_t s) {
+    const long total = (long)a.B * a.H * a.W;
+    hipLaunchKernelGGL(heat_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_heat_prob_from_raw(const HeatArgs& a, hipStream_t s) {
+    const long total = (long)a.B * a.H * a.W;
+    hipLaunchKernelGGL(heat_prob_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// refineHeatMap (feature/src/PPGExtractor.cpp:540-578) on the tile grid of :243-256.
+// One work-group per tile (tiles are refine_sz^2, the last row/column of tiles absorbs the
+// remainder, so at most (2*sz-1)^2 pixels).  The row-major list of values > valid_thresh is rebuilt
+// in LDS in the reference's order (needed for the percentile probe on the UNSORTED list, :557),
+// ranked by counting, and the top-30 % mean is accumulated in double in sorted order by one lane —
+// the same additions in the same order as std::accumulate(…, 0.0).
+// =====================================================================================
+constexpr int RF_MAXPIX = 1024;  // (2*16-1)^2 = 961
+
+__global__ __launch_bounds__(256) void refine_kernel(HeatArgs a) {
+    __shared__ float vals[RF_MAXPIX];
+    __shared__ float sorted[RF_MAXPIX];
+    __shared__ int wave_cnt[4];
+    __shared__ int s_n;
+    __shared__ float s_ave;
+    __shared__ int s_action;  // 0 leave, 1 zero, 2 rescale
+    const int S = a.refine_sz;
+    const int gxn = a.W / S, gyn = a.H / S;
+    const int tj = blockIdx.x % gxn, ti = (blockIdx.x / gxn) % gyn, b = blockIdx.x / (gxn * gyn);
+    const int h0 = ti * S, w0 = tj * S;
+    const int h1 = ti == gyn - 1 ? a.H : (ti + 1) * S, w1 = tj == gxn - 1 ? a.W : (tj + 1) * S;
+    const int segH = h1 - h0, segW = w1 - w0, area = segH * segW;
+    const float* src = a.prob + (size_t)b * a.H * a.W;
+    float* dst = a.refined + (size_t)b * a.H * a.W;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    // ordered compaction, 256 pixels per pass
+    int base = 0;
+    for (int p0 = 0; p0 < area; p0 += 256) {
+        const int p = p0 + tid;
+        float v = 0.f;
+        bool ok = false;
+        if (p < area) {
+            v = src[(size_t)(h0 + p / segW) * a.W + w0 + p % segW];
+            ok = v > a.valid_thresh;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int wv = 0; wv < wave; wv++) off += wave_cnt[wv];
+        if (ok) vals[off + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    const int n = base;
+    if (tid == 0) {
+        int action = 2;
+        const int valCount = (int)(a.valid_ratio * (float)n);
+        if (valCount < 1) action = 0;
+        else if ((double)n >= (double)(segH * segW) * 0.9 && (double)vals[(size_t)((double)n * 0.9)] > 0.1) action = 1;
+        s_action = action;
+        s_n = valCount;
+    }
+    __syncthreads();
+    const int action = s_action, valCount = s_n;
+    if (action == 2) {
+        for (int k = tid; k < n; k += 256) {
+            const float v = vals[k];
+            int rank = 0;
+            for (int j = 0; j < n; j++) {
+                const float u = vals[j];
+                rank += (u > v) || (u == v && j < k);
+            }
+            sorted[rank] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int k = 0; k < valCount; k++) acc += (double)sorted[k];
+            s_ave = (float)(acc / (double)(float)valCount);
+        }
+        __syncthreads();
+    }
+    const float ave = s_ave;
+    for (int p = tid; p < area; p += 256) {
+        const size_t o = (size_t)(h0 + p / segW) * a.W + w0 + p % segW;
+        const float v = src[o];
+        float r = v;
+        if (action == 1) r = 0.f;
+        else if (action == 2) {
+            if (v > a.valid_thresh) {
+                const float ns = v / ave;
+                r = (double)ns > 1.0 ? 1.0f : ns;
+            } else r = 0.f;
+        }
+        dst[o] = r;
+    }
+}
+
+hipError_t launch_refine(const HeatArgs& a, hipStream_t s) {
+    const int S = a.refine_sz;
+    if (S < 1 || (2 * S - 1) * (2 * S - 1) > RF_MAXPIX) return hipErrorInvalidValue;
+    const int tiles = (a.W / S) * (a.H / S) * a.B;
+    hipLaunchKernelGGL(refine_kernel, dim3(tiles), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// detectLines, state-independent part (feature/src/PPGExtractor.cpp:290-313 and :367-389).
+// For every in-image pair i < j: the three-point heat probe (:304-313).  Survivors are appended
+// (unordered) with the two scores the reference computes later for lines that are still alive
+// (heatMapInlierRate :484-497, heatMapLineScore :502-512); both depend only on the end points, so
+// they can be evaluated up front.  The order-dependent overlap / collinearity logic consumes this
+// list on the host after sorting it by (i, j).
+// =====================================================================================
+__constant__ float kInvSampleGap[4] = {0.3333f, 0.200f, 0.1427f, 0.1111f};  // PPGExtractor.cpp:19
+
+__device__ inline float heat_at(const float* heat, int W, int y, int x) { return heat[(size_t)y * W + x]; }
+
+__global__ __launch_bounds__(256) void line_pairs_kernel(LineArgs a) {
+    const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    int* cnt = a.counters + b * 8;
+    const int n = cnt[3];
+    if (i >= n || j >= n || j <= i) return;
+    const uint8_t* out = a.kp_out + (size_t)b * a.max_num;
+    if (out[i] || out[j]) return;
+    const float* un = a.kp_un + (size_t)b * a.max_num * 2;
+    const float* heat = a.heat + (size_t)b * a.H * a.W;
+    const float ix = un[2 * i], iy = un[2 * i + 1], jx = un[2 * j], jy = un[2 * j + 1];
+    const float c1x = jx * 0.2f + ix * 0.8f, c1y = jy * 0.2f + iy * 0.8f;
+    if (heat_at(heat, a.W, (int)((double)c1y + 0.5), (int)((double)c1x + 0.5)) < a.heat_thresh) return;
+    const float c2x = jx * 0.8f + ix * 0.2f, c2y = jy * 0.8f + iy * 0.2f;
+    if (heat_at(heat, a.W, (int)((double)c2y + 0.5), (int)((double)c2x + 0.5)) < a.heat_thresh) return;
+    const float c3x = jx * 0.5f + ix * 0.5f, c3y = jy * 0.5f + iy * 0.5f;
+    if (heat_at(heat, a.W, (int)((double)c3y + 0.5), (int)((double)c3x + 0.5)) < a.heat_thresh) return;
+    const int k = atomicAdd(&cnt[2], 1);
+    if (k < a.cand_cap) a.cand_ij[(size_t)b * a.cand_cap + k] = ((uint32_t)i << 16) | (uint32_t)j;
+}
+
+__global__ __launch_bounds__(256) void line_score_kernel(LineArgs a) {
+    const int b = blockIdx.y;
+    const int* cnt = a.counters + b * 8;
+    const int nc = min(cnt[2], a.cand_cap);
+    const float* un = a.kp_un + (size_t)b * a.max_num * 2;
+    const float* heat = a.heat + (size_t)b * a.H * a.W;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < nc; k += gridDim.x * 256) {
+        const uint32_t ij = a.cand_ij[(size_t)b * a.cand_cap + k];
+        const int i = ij >> 16, j = ij & 0xFFFF;
+        // ps = start (i), pe = end (j)
+        const float psx = un[2 * i], psy = un[2 * i + 1], pex = un[2 * j], pey = un[2 * j + 1];
+        const float dx = psx - pex, dy = psy - pey;
+        const float dist = __fsqrt_rn(dx * dx + dy * dy);
+        const int lenLevel = (int)((double)(dist * a.inv_scale) * 4.0);
+        const int segNum = (int)(dist * kInvSampleGap[lenLevel < 0 ? 0 : (lenLevel > 3 ? 3 : lenLevel)]);
+        const float step = (float)(1.0 / (double)(float)segNum);
+        int inl = 0;
+        float sum = 0.f;
+        for (int t = 1; t < segNum; t++) {
+            const float sx = psx * step * (float)t + pex * step * (float)(segNum - t);
+            const float sy = psy * step * (float)t + pey * step * (float)(segNum - t);
+            const int px = (int)((double)sx + 0.5), py = (int)((double)sy + 0.5);
+            if (heat_at(heat, a.W, py, px) > a.heat_thresh) inl++;
+            // bilinearInterpolation, PPGExtractor.cpp:580-589
+            const int x1 = (int)sx, x2 = x1 + 1, y1 = (int)sy, y2 = y1 + 1;
+            const float d1 = ((float)x2 - sx) * heat_at(heat, a.W, y1, x1) + (sx - (float)x1) * heat_at(heat, a.W, y1, x2);
+            const float d2 = ((float)x2 - sx) * heat_at(heat, a.W, y2, x1) + (sx - (float)x1) * heat_at(heat, a.W, y2, x2);
+            sum += ((float)y2 - sy) * d1 + (sy - (float)y1) * d2;
+        }
+        float* o = a.cand_sc + ((size_t)b * a.cand_cap + k) * 2;
+        o[0] = (float)inl / (float)(segNum - 1);
+        o[1] = sum / (float)(segNum - 1);
+    }
+}
+
+hipError_t launch_line_candidates(const LineArgs& a, hipStream_t s) {
+    dim3 g1((a.max_num + 255) / 256, a.max_num, a.B);
+    hipLaunchKernelGGL(line_pairs_kernel, g1, dim3(256), 0, s, a);
+    dim3 g2(64, a.B);
+    hipLaunchKernelGGL(line_score_kernel, g2, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// genPointDescriptor (feature/src/PPGExtractor.cpp:515-538): grid_sampler(bilinear, zeros,
+// align_corners=false) of the raw descriptor map at the integer key-point positions, then
+// F::normalize(dim=1).  One wave per key point, four channels per lane (1 KiB coalesced per tap).
+// =====================================================================================
+__global__ __launch_bounds__(256) void desc_sample_kernel(DescArgs a) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = a.counters[b * 8 + 3];
+    if (k >= n) return;
+    float* o = a.desc + ((size_t)b * a.max_num + k) * 256 + lane * 4;
+    if (n < 10) {  // PPGExtractor.cpp:520-524
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)o = z;
+        return;
+    }
+    const int w = a.W / 8, h = a.H / 8;
+    const int32_t* xy = a.kp_xy + ((size_t)b * a.max_num + k) * 2;
+    // :530-531: f32 / f32, then "* 2. - 1." in double, stored as f32
+    const float gx = (float)((double)((float)xy[0] / (float)a.W) * 2. - 1.);
+    const float gy = (float)((double)((float)xy[1] / (float)a.H) * 2. - 1.);
+    const float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f, iy = ((gy + 1.f) * (float)h - 1.f) / 2.f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float nw = ((float)x1 - ix) * ((float)y1 - iy), ne = (ix - (float)x0) * ((float)y1 - iy);
+    const float sw = ((float)x1 - ix) * (iy - (float)y0), se = (ix - (float)x0) * (iy - (float)y0);
+    const float* dm = a.descmap + (size_t)b * h * w * 256 + lane * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    auto tap = [&](int y, int x, float wt) {
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+            const f32x4 t = *(const f32x4*)(dm + ((size_t)y * w + x) * 256);
+            v[0] = v[0] + t[0] * wt; v[1] = v[1] + t[1] * wt; v[2] = v[2] + t[2] * wt; v[3] = v[3] + t[3] * wt;
+        }
+    };
+    tap(y0, x0, nw); tap(y0, x1, ne); tap(y1, x0, sw); tap(y1, x1, se);
+    double ss = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+    ss = wave_sum_d(ss);
+    const float nrm = (float)sqrt(ss);
+    const float den = nrm > 1e-12f ? nrm : 1e-12f;
+    v[0] = v[0] / den; v[1] = v[1] / den; v[2] = v[2] / den; v[3] = v[3] / den;
+    *(f32x4*)o = v;
+}
+
+hipError_t launch_desc_sample(const DescArgs& a, hipStream_t s) {
+    dim3 grid((a.max_num + 3) / 4, a.B);
+    hipLaunchKernelGGL(desc_sample_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// DescriptorDistance (feature/src/MapPoint.cpp:22-29) for all pairs of two descriptor sets.
+// 64x64 output tile per work-group, 4x4 outputs per thread, 16-deep slices through LDS.  Each
+// output is one fmaf chain over d = 0..dim-1 in order, then a correctly rounded square root, so the
+// value does not depend on the tiling.
+// =====================================================================================
+constexpr int DT = 64, DK = 16;
+
+__global__ __launch_bounds__(256) void dist_matrix_kernel(const float* __restrict__ A, int nA, const float* __restrict__ B,
+                                                          int nB, int dim, float* __restrict__ D, int ldd,
+                                                          const int* nA_dev, const int* nB_dev) {
+    if (nA_dev) nA = *nA_dev;
+    if (nB_dev) nB = *nB_dev;
+    const int r0 = blockIdx.y * DT, c0 = blockIdx.x * DT;
+    if (r0 >= nA || c0 >= nB) return;
+    __shared__ float As[DK][DT + 4];
+    __shared__ float Bs[DK][DT + 4];
+    const int tid = threadIdx.x, tr = tid / 16, tc = tid % 16;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+    // staging: thread loads one float4 of A and one of B per slice: row = tid/4, k4 = tid%4
+    const int lr = tid >> 2, lk = (tid & 3) * 4;
+    for (int k0 = 0; k0 < dim; k0 += DK) {
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + lr < nA) va = *(const f32x4*)(A + (size_t)(r0 + lr) * dim + k0 + lk);
+        if (c0 + lr < nB) vb = *(const f32x4*)(B + (size_t)(c0 + lr) * dim + k0 + lk);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) { As[lk + q][lr] = va[q]; Bs[lk + q][lr] = vb[q]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DK; k++) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) av[i] = As[k][tr * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[j] = Bs[k][tc * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float d = av[i] - bv[j];
+                    acc[i][j] = fmaf(d, d, acc[i][j]);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = r0 + tr * 4 + i, c = c0 + tc * 4 + j;
+            if (r < nA && c < nB) D[(size_t)r * ldd + c] = __fsqrt_rn(acc[i][j]);
+        }
+}
+
+hipError_t launch_dist_matrix(const float* A, int nA, const float* B, int nB, int dim, float* D, int ldd, hipStream_t s) {
+    if (nA <= 0 || nB <= 0) return hipSuccess;
+    dim3 grid((nB + DT - 1) / DT, (nA + DT - 1) / DT);
+    hipLaunchKernelGGL(dist_matrix_kernel, grid, dim3(256), 0, s, A, nA, B, nB, dim, D, ldd, (const int*)nullptr,
+                       (const int*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_matrix_dev(const float* A, const int* nA_dev, int maxA, const float* B, const int* nB_dev, int maxB,
+                                  int dim, float* D, int ldd, hipStream_t s) {
+    dim3 grid((maxB + DT - 1) / DT, (maxA + DT - 1) / DT);
+    hipLaunchKernelGGL(dist_matrix_kernel, grid, dim3(256), 0, s, A, maxA, B, maxB, dim, D, ldd, nA_dev, nB_dev);
+    return hipGetLastError();
+}
+
+// one lane per (row, candidate) pair of a CSR candidate list; same fmaf chain
+__global__ __launch_bounds__(256) void dist_csr_kernel(const float* __restrict__ A, int nA, const float* __restrict__ B, int dim,
+                                                       const int32_t* __restrict__ cand_off,
+                                                       const int32_t* __restrict__ cand_idx, float* __restrict__ Dc) {
+    const int row = blockIdx.x;
+    if (row >= nA) return;
+    const int o0 = cand_off[row], o1 = cand_off[row + 1];
+    const float* a = A + (size_t)row * dim;
+    for (int k = o0 + threadIdx.x; k < o1; k += 256) {
+        const float* bb = B + (size_t)cand_idx[k] * dim;
+        float acc = 0.f;
+        for (int d = 0; d < dim; d += 4) {
+            const f32x4 x = *(const f32x4*)(a + d), y = *(const f32x4*)(bb + d);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float t = x[q] - y[q];
+                acc = fmaf(t, t, acc);
+            }
+        }
+        Dc[k] = __fsqrt_rn(acc);
+    }
+}
+
+hipError_t launch_dist_csr(const float* A, int nA, const float* B, int dim, const int32_t* cand_off,
+                           const int32_t* cand_idx, float* Dc, hipStream_t s) {
+    if (nA <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dist_csr_kernel, dim3(nA), dim3(256), 0, s, A, nA, B, dim, cand_off, cand_idx, Dc);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Nearest-neighbour reductions with wavefront shuffles.
+//
+// Sequential semantics being reproduced (e.g. matching/src/Matcher.cpp:607-627): walk the candidates
+// in order; `dist < best` shifts best into second; `else if dist < second` updates second.  The
+// result is (min, first position of the min, second smallest of the multiset), which merges
+// associatively — so lanes scan strided sub-lists and combine with shuffles.
+// =====================================================================================
+struct Best2 {
+    float b, b2;
+    int pos;  // position in candidate order (for ties), -1 when empty
+    int idx;  // B row
+};
+
+__device__ inline Best2 best2_merge(Best2 x, Best2 y) {
+    const bool xwins = x.b < y.b || (x.b == y.b && (unsigned)x.pos < (unsigned)y.pos);
+    Best2 r;
+    if (xwins) { r.b = x.b; r.pos = x.pos; r.idx = x.idx; r.b2 = fminf(x.b2, y.b); }
+    else { r.b = y.b; r.pos = y.pos; r.idx = y.idx; r.b2 = fminf(y.b2, x.b); }
+    return r;
+}
+
+__device__ inline Best2 best2_wave(Best2 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Best2 t;
+        t.b = __shfl_xor(v.b, o); t.b2 = __shfl_xor(v.b2, o);
+        t.pos = __shfl_xor(v.pos, o); t.idx = __shfl_xor(v.idx, o);
+        v = best2_merge(v, t);
+    }
+    return v;
+}
+
+__device__ inline void row_candidates(const MatchArgs& a, int row, int nB, const float** drow, const int32_t** irow, int* cnt) {
+    if (a.ldd > 0) { *drow = a.D + (size_t)row * a.ldd; *irow = nullptr; *cnt = nB; }
+    else { const int o0 = a.cand_off[row]; *drow = a.D + o0; *irow = a.cand_idx + o0; *cnt = a.cand_off[row + 1] - o0; }
+}
+
+// PLAIN: one wave per A row
+__global__ __launch_bounds__(256) void match_plain_kernel(MatchArgs a) {
+    const int nA = a.nA_dev ? *a.nA_dev : a.nA, nB = a.nB_dev ? *a.nB_dev : a.nB;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nA) return;
+    const float* drow; const int32_t* irow; int cnt;
+    row_candidates(a, row, nB, &drow, &irow, &cnt);
+    Best2 v = {1e6f, 1e6f, -1, -1};
+    for (int k = lane; k < cnt; k += 64) {
+        const int idx = irow ? irow[k] : k;
+        if (a.skipB && a.skipB[idx]) continue;
+        const float d = drow[k];
+        if (d < v.b) { v.b2 = v.b; v.b = d; v.pos = k; v.idx = idx; }
+        else if (d < v.b2) v.b2 = d;
+    }
+    v = best2_wave(v);
+    if (lane == 0) { a.match12[row] = v.idx; a.best[row] = v.b; a.second[row] = v.b2; }
+}
+
+hipError_t launch_match_plain(const MatchArgs& a, hipStream_t s) {
+    if (a.nA <= 0) return hipSuccess;
+    hipLaunchKernelGGL(match_plain_kernel, dim3((a.nA + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// INIT step 1: per A row, the 8 nearest candidates ordered by (distance, candidate position),
+// ignoring claims.  One wave per row: every lane keeps a sorted list of its own 8 best, then the
+// wave pops the global minimum 8 times.
+constexpr int TOPK = 8;
+
+__global__ __launch_bounds__(256) void match_topk_kernel(MatchArgs a) {
+    const int nA = a.nA_dev ? *a.nA_dev : a.nA, nB = a.nB_dev ? *a.nB_dev : a.nB;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nA) return;
+    const float* drow; const int32_t* irow; int cnt;
+    row_candidates(a, row, nB, &drow, &irow, &cnt);
+    float ld[TOPK];
+    int lp[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) { ld[t] = 3e38f; lp[t] = 0x7FFFFFFF; }
+    for (int k = lane; k < cnt; k += 64) {
+        const int idx = irow ? irow[k] : k;
+        if (a.skipB && a.skipB[idx]) continue;
+        float d = drow[k];
+        int p = k;
+        // insertion into the sorted list; positions ascend within a lane, so ties keep the earlier one first
+#pragma unroll
+        for (int t = 0; t < TOPK; t++) {
+            if (d < ld[t]) {
+                const float td = ld[t]; const int tp = lp[t];
+                ld[t] = d; lp[t] = p; d = td; p = tp;
+            }
+        }
+    }
+    for (int t = 0; t < TOPK; t++) {
+        // wave argmin over list heads
+        float d = ld[0];
+        int p = lp[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(d, o);
+            const int op = __shfl_xor(p, o);
+            if (od < d || (od == d && op < p)) { d = od; p = op; }
+        }
+        if (lp[0] == p && p != 0x7FFFFFFF) {  // this lane owned the winner: pop
+#pragma unroll
+            for (int q = 0; q < TOPK - 1; q++) { ld[q] = ld[q + 1]; lp[q] = lp[q + 1]; }
+            ld[TOPK - 1] = 3e38f; lp[TOPK - 1] = 0x7FFFFFFF;
+        }
+        if (lane == 0) {
+            const bool valid = p != 0x7FFFFFFF;
+            a.topk_dist[(size_t)row * TOPK + t] = valid ? d : 3e38f;
+            a.topk_idx[(size_t)row * TOPK + t] = valid ? (irow ? irow[p] : p) : -1;
+        }
+    }
+}
+
+// INIT step 2: the reference's sequential pass over i1 (Matcher.cpp:591-644) by ONE wave.
+// A claimed F2 feature stores (int)bestDist == 0 in vMatchedDistance (:588, :640), so the test
+// `vMatchedDistance[i2] <= dist` (:614) skips it for every later i1; the un-claim branch (:633-637)
+// can therefore never run.  Rows whose 8-entry list cannot supply two unclaimed candidates while the
+// row has more candidates fall back to a full scan of the row by the wave.  The claim bitmap lives
+// in LDS and the lists are fetched eight rows at a time, so a row costs LDS latency only.
+constexpr int CLAIM_WORDS = 2048;  // up to 65536 B rows
+
+__global__ __launch_bounds__(64) void match_init_resolve_kernel(MatchArgs a) {
+    __shared__ uint32_t claimed[CLAIM_WORDS];
+    const int nA = a.nA_dev ? *a.nA_dev : a.nA, nB = a.nB_dev ? *a.nB_dev : a.nB;
+    const int lane = threadIdx.x;
+    for (int k = lane; k < CLAIM_WORDS; k += 64) claimed[k] = 0;
+    __syncthreads();
+    int nmatches = 0;
+    for (int r0 = 0; r0 < nA; r0 += 8) {
+        // lane -> (row r0 + lane/8, entry lane%8): one coalesced 256-B read per array
+        float dv = 3e38f;
+        int iv = -1;
+        if (r0 + (lane >> 3) < nA) {
+            dv = a.topk_dist[(size_t)r0 * TOPK + lane];
+            iv = a.topk_idx[(size_t)r0 * TOPK + lane];
+        }
+        const int rows = min(8, nA - r0);
+        for (int rr = 0; rr < rows; rr++) {
+            const int row = r0 + rr;
+            const int srcl = rr * 8 + (lane & 7);
+            float d = __shfl(dv, srcl);
+            int idx = __shfl(iv, srcl);
+            if (lane >= TOPK) { d = 3e38f; idx = -1; }
+            const bool listed = idx >= 0;
+            bool free_ = false;
+            if (listed) free_ = !((claimed[idx >> 5] >> (idx & 31)) & 1u);
+            const unsigned long long mlist = __ballot(listed), mfree = __ballot(free_);
+            const int nlisted = __popcll(mlist), nfree = __popcll(mfree);
+            float best = 1e6f, second = 1e6f;
+            int bidx = -1;
+            if (nfree >= 2 || nlisted < TOPK) {
+                // the list suffices: first two unclaimed entries in (distance, position) order
+                if (nfree >= 1) {
+                    const int l0 = __ffsll((long long)mfree) - 1;
+                    best = __shfl(d, l0);
+                    bidx = __shfl(idx, l0);
+                    const unsigned long long rest = mfree & ~(1ull << l0);
+                    if (rest) second = __shfl(d, __ffsll((long long)rest) - 1);
+                }
+            } else {
+                const float* drow; const int32_t* irow; int cnt;
+                row_candidates(a, row, nB, &drow, &irow, &cnt);
+                Best2 v = {1e6f, 1e6f, -1, -1};
+                for (int k = lane; k < cnt; k += 64) {
+                    const int id = irow ? irow[k] : k;
+                    if (a.skipB && a.skipB[id]) continue;
+                    if ((claimed[id >> 5] >> (id & 31)) & 1u) continue;
+                    const float dd = drow[k];
+                    if (dd < v.b) { v.b2 = v.b; v.b = dd; v.pos = k; v.idx = id; }
+                    else if (dd < v.b2) v.b2 = dd;
+                }
+                v = best2_wave(v);
+                best = v.b; second = v.b2; bidx = v.idx;
+            }
+            int m = -1;
+            if (bidx >= 0 && best <= a.th && best < second * a.ratio) {
+                m = bidx;
+                nmatches++;
+                if (lane == 0) claimed[bidx >> 5] |= 1u << (bidx & 31);
+            }
+            if (lane == 0) { a.match12[row] = m; a.best[row] = best; a.second[row] = second; }
+            __syncthreads();  // single wave: the claim is in LDS before the next row reads the bitmap
+        }
+    }
+    if (lane == 0) *a.n_matches = nmatches;
+}
+
+hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
+    const int rows = a.nA;
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(match_topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(match_init_resolve_kernel, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ppg

@@ -1,0 +1,333 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI of libppgfront.so.
+
+Three kinds of check:
+  * CNN tensors against the golden outputs of the reference's TorchScript nets (tolerance: fp32
+    summation-order noise, far inside the 1e-3 descriptor bar);
+  * stage-wise: the golden tensors are injected into the context and each post-processing stage must
+    reproduce the oracle's integer outputs EXACTLY (same inputs => no rounding excuse);
+  * end to end against the oracle / goldens, where near-tied key points may swap (see conftest).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, assert_keypoints_equivalent, edge_coord_set
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["cnn_96x128_s1_sparse.npz", "cnn_128x160_s7_dense.npz", "cnn_64x96_s3_sparse.npz"]
+FULL = [("full_480x640_s1_sparse.npz", "sparse"), ("full_480x640_s11_dense.npz", "dense"), ("full_512x512_s5_sparse.npz", "sparse")]
+
+_ctx_cache = {}
+
+
+def get_ctx(pkg, W, H, max_num=500, batch=1):
+    key = (W, H, max_num, batch)
+    if key not in _ctx_cache:
+        if len(_ctx_cache) > 6:
+            k0 = next(iter(_ctx_cache))
+            _ctx_cache.pop(k0).close()
+        _ctx_cache[key] = pkg.Context(pkg.default_config(W, H, max_batch=batch, max_num=max_num))
+    return _ctx_cache[key]
+
+
+def nhwc(a):
+    return np.ascontiguousarray(np.transpose(a, (1, 2, 0)))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_cnn_tensors_vs_reference_nets(name, pkg):
+    g = golden(name)
+    H, W = g["img"].shape
+    ctx = get_ctx(pkg, W, H)
+    ctx.inference([g["img"]])
+    ctx.detect_keypoints(1)
+    for which, k, rel in ((pkg.T_FEAT, "feat", 4e-6), (pkg.T_JUNC, "junc", 4e-6), (pkg.T_HEAT_RAW, "heat", 1e-5),
+                          (pkg.T_DESCMAP, "desc", 4e-6)):
+        got = ctx.read_tensor(which)
+        ref = nhwc(g[k])
+        err, scale = float(np.abs(got - ref).max()), float(np.abs(ref).max())
+        assert err <= rel * scale, (k, err, scale)
+    assert float(np.abs(ctx.read_tensor(pkg.T_SCORE) - g["score"]).max()) < 1e-5
+    assert float(np.abs(ctx.read_tensor(pkg.T_HEAT) - g["prob"]).max()) < 2e-5
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_stages_exact_on_injected_tensors(name, pkg, orc):
+    g = golden(name)
+    H, W = g["img"].shape
+    ctx = get_ctx(pkg, W, H)
+    ctx.inference([g["img"]])
+    ctx.write_tensor(pkg.T_SCORE, g["score"])
+    ctx.write_tensor(pkg.T_HEAT, g["prob"])
+    ctx.write_tensor(pkg.T_DESCMAP, nhwc(g["desc"]))
+    ctx.detect_keypoints(1)
+    ctx.detect_lines(1)
+    ctx.gen_descriptors(1)
+    r = ctx.collect(1)[0]
+    assert np.array_equal(r["xy"], g["kp_xy"])
+    assert np.array_equal(r["score"], g["kp_score"])
+    assert np.array_equal(r["un"], g["kp_un"])
+    assert np.array_equal(r["out"], g["kp_out"])
+    assert np.array_equal(ctx.read_tensor(pkg.T_HEAT_REFINED), g["refined"])  # bit-exact refineHeatMap
+    assert np.array_equal(r["edge_idx"], g["edge_idx"])
+    assert np.array_equal(r["edge_score"], g["edge_score"], equal_nan=True)
+    assert np.array_equal(r["conn_off"], g["conn_off"]) and np.array_equal(r["conn_idx"], g["conn_idx"])
+    assert np.array_equal(r["coline_off"], g["coline_off"]) and np.array_equal(r["coline_pairs"], g["coline_pairs"])
+    # K11/K12 vs torch grid_sampler + normalize (north-star tolerance 1e-3)
+    assert float(np.linalg.norm(r["desc"] - g["kp_desc"], axis=1).max()) < 1e-5
+
+
+@pytest.mark.parametrize("name,kind", FULL)
+def test_full_frame_vs_golden(name, kind, pkg, synth):
+    g = golden(name)
+    H, W, seed, maxnum = [int(v) for v in g["meta"]]
+    ctx = get_ctx(pkg, W, H, maxnum)
+    for t in (0, 1):
+        img = synth.make_frame(H, W, seed, t, kind)
+        r = ctx.extract(img)
+        assert float(np.abs(ctx.read_tensor(pkg.T_SCORE)[::4, ::4] - g[f"score_sub_{t}"]).max()) < 1e-5
+        assert float(np.mean(np.abs(ctx.read_tensor(pkg.T_HEAT_REFINED)[::4, ::4] - g[f"refined_sub_{t}"]) > 1e-4)) < 1e-3
+        swaps = assert_keypoints_equivalent(r["xy"], r["score"], g[f"kp_xy_{t}"], g[f"kp_score_{t}"])
+        ea, eb = edge_coord_set(r["edge_idx"], r["xy"]), edge_coord_set(g[f"edge_idx_{t}"], g[f"kp_xy_{t}"])
+        assert len(ea ^ eb) <= 2, len(ea ^ eb)
+        if swaps == 0:
+            # descriptors: ||d_gpu - d_ref||_2 <= 1e-3 is the bar; fp32 MFMA lands near 1e-5
+            assert float(np.linalg.norm(r["desc"] - g[f"kp_desc_{t}"], axis=1).max()) < 1e-4
+            if len(ea ^ eb) == 0:
+                assert np.array_equal(r["edge_idx"], g[f"edge_idx_{t}"])
+
+
+def test_ragged_sizes_vs_oracle(pkg, orc, onet, synth):
+    """W not a multiple of the 32-px conv tile, H not of 8 rows x 2; refine tiles with remainders."""
+    for (H, W, seed) in ((72, 104, 21), (480, 752, 22)):
+        img = synth.make_frame(H, W, seed, 0, "sparse")
+        ctx = get_ctx(pkg, W, H)
+        r = ctx.extract(img)
+        cfg = orc.default_cfg(W, H)
+        t = onet.inference(img)
+        feat = ctx.read_tensor(pkg.T_FEAT)
+        assert float(np.abs(feat - nhwc(t["feat"])).max()) <= 4e-6 * float(np.abs(t["feat"]).max())
+        # post-processing exact on the GPU's own tensors
+        kp = orc.detect_keypoints(cfg, ctx.read_tensor(pkg.T_SCORE))
+        assert np.array_equal(r["xy"], kp["xy"]) and np.array_equal(r["un"], kp["un"])
+        refined = orc.refine_heat(cfg, ctx.read_tensor(pkg.T_HEAT))
+        assert np.array_equal(ctx.read_tensor(pkg.T_HEAT_REFINED), refined)
+        ln = orc.detect_lines(cfg, refined, kp["un"], kp["out"])
+        assert np.array_equal(r["edge_idx"], ln["edge_idx"]) and np.array_equal(r["conn_idx"], ln["conn_idx"])
+        assert np.array_equal(r["coline_pairs"], ln["coline_pairs"])
+        d = orc.gen_descriptors(cfg, np.transpose(ctx.read_tensor(pkg.T_DESCMAP), (2, 0, 1)), kp["xy"])
+        assert float(np.linalg.norm(r["desc"] - d, axis=1).max()) < 1e-5
+
+
+def test_full_size_postprocessing_exact_on_gpu_tensors(pkg, orc, synth):
+    """BASELINE sizes: every integer output equals the oracle's when both start from the GPU's CNN tensors."""
+    for (H, W, seed, kind, maxnum) in ((480, 640, 31, "sparse", 500), (480, 640, 32, "dense", 1024), (512, 512, 33, "dense", 1024)):
+        ctx = get_ctx(pkg, W, H, maxnum)
+        img = synth.make_frame(H, W, seed, 0, kind)
+        r = ctx.extract(img)
+        cfg = orc.default_cfg(W, H, maxnum)
+        kp = orc.detect_keypoints(cfg, ctx.read_tensor(pkg.T_SCORE))
+        assert r["n"] == kp["n"]
+        assert np.array_equal(r["xy"], kp["xy"]) and np.array_equal(r["score"], kp["score"])
+        refined = orc.refine_heat(cfg, ctx.read_tensor(pkg.T_HEAT))
+        assert np.array_equal(ctx.read_tensor(pkg.T_HEAT_REFINED), refined)
+        ln = orc.detect_lines(cfg, refined, kp["un"], kp["out"])
+        assert np.array_equal(r["edge_idx"], ln["edge_idx"])
+        assert np.array_equal(r["edge_score"], ln["edge_score"], equal_nan=True)
+        assert np.array_equal(r["conn_off"], ln["conn_off"]) and np.array_equal(r["conn_idx"], ln["conn_idx"])
+        assert np.array_equal(r["coline_off"], ln["coline_off"]) and np.array_equal(r["coline_pairs"], ln["coline_pairs"])
+
+
+def test_batch_equals_single(pkg, synth):
+    H, W = 96, 128
+    imgs = [synth.make_frame(H, W, 40 + k, 0, "sparse" if k % 2 else "dense") for k in range(4)]
+    one = get_ctx(pkg, W, H)
+    singles = [one.extract(i) for i in imgs]
+    ctx = get_ctx(pkg, W, H, batch=4)
+    for r, s in zip(ctx.extract_batch(imgs), singles):
+        for k in ("xy", "score", "un", "out", "desc", "edge_idx", "conn_idx", "coline_pairs"):
+            assert np.array_equal(r[k], s[k], equal_nan=True), k
+    # partial batch and idempotence
+    again = ctx.extract_batch(imgs[:3])
+    for r, s in zip(again, singles[:3]):
+        assert np.array_equal(r["xy"], s["xy"]) and np.array_equal(r["desc"], s["desc"])
+
+
+def test_degenerate_frames(pkg):
+    H, W = 64, 96
+    ctx = get_ctx(pkg, W, H)
+    r = ctx.extract(np.full((H, W), 128, np.uint8))  # no junctions: N = 0, empty graph
+    assert r["n"] == 0 and r["n_edges"] == 0 and list(r["conn_off"]) == [0]
+    # fewer than 10 key points: all-zero descriptors (PPGExtractor.cpp:520-524)
+    img = np.full((H, W), 128, np.uint8)
+    img[20:44, 30:66] = 255
+    r = ctx.extract(img)
+    assert 0 < r["n"] < 10 and not r["desc"].any()
+
+
+def test_create_rejects_bad_arguments(pkg):
+    with pytest.raises(pkg.PPGError, match="multiples of 8"):
+        pkg.Context(pkg.default_config(100, 60))
+    with pytest.raises(pkg.PPGError, match="cannot open"):
+        pkg.Context(pkg.default_config(64, 64, weights="/nonexistent.bin"))
+    ctx = get_ctx(pkg, 96, 64)
+    with pytest.raises(ValueError):
+        ctx.extract(np.zeros((10, 10), np.uint8))
+    with pytest.raises(pkg.PPGError, match="max_batch"):
+        ctx.extract_batch([np.zeros((64, 96), np.uint8)] * 2)
+
+
+# ------------------------------- matching -------------------------------
+
+def unit_rows(rng, n):
+    a = rng.normal(size=(n, 256)).astype(np.float32)
+    return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_dist_matrix_bit_exact(pkg, orc):
+    rng = np.random.default_rng(1)
+    ctx = get_ctx(pkg, 96, 64)
+    for nA, nB in ((1, 1), (7, 130), (200, 65), (64, 64)):
+        A, B = unit_rows(rng, nA), unit_rows(rng, nB)
+        D = ctx.dist_matrix(A, B)
+        for i, j in {(0, 0), (nA - 1, nB - 1), (nA // 2, nB // 3)}:
+            assert D[i, j] == np.float32(orc.descriptor_distance(A[i], B[j]))
+        ref = np.sqrt(((A[:, None, :].astype(np.float64) - B[None]) ** 2).sum(-1))
+        assert float(np.abs(D - ref).max()) < 1e-6
+
+
+def make_pair(rng, n, noise=0.05, shuffle=True):
+    A = unit_rows(rng, n)
+    perm = rng.permutation(n) if shuffle else np.arange(n)
+    B = A[perm] + noise * rng.normal(size=(n, 256)).astype(np.float32) / 16
+    B = (B / np.linalg.norm(B, axis=1, keepdims=True)).astype(np.float32)
+    return A, B, perm
+
+
+def test_match_plain_vs_oracle(pkg, orc):
+    rng = np.random.default_rng(2)
+    ctx = get_ctx(pkg, 96, 64)
+    A, B, _ = make_pair(rng, 150)
+    B[17] = B[3]  # exact tie: the first candidate in order must win
+    skip = (rng.random(150) < 0.1).astype(np.uint8)
+    off = [0]
+    idx = []
+    for i in range(150):
+        k = int(rng.integers(0, 40))
+        idx += list(rng.choice(150, size=k, replace=False))
+        off.append(len(idx))
+    m, best, second, _ = ctx.match_nn(A, B, np.array(off), np.array(idx), skip, mode=pkg.MATCH_PLAIN)
+    import ctypes as C
+    for i in range(150):
+        cand = np.array(idx[off[i]:off[i + 1]], np.int32)
+        b, s = C.c_float(), C.c_float()
+        bi = orc.lib().ppgo_window_nn(A[i].ctypes.data_as(C.c_void_p), 256, B.ctypes.data_as(C.c_void_p),
+                                      cand.ctypes.data_as(C.c_void_p), len(cand), skip.ctypes.data_as(C.c_void_p),
+                                      C.byref(b), C.byref(s))
+        assert (m[i], best[i], second[i]) == (bi, np.float32(b.value), np.float32(s.value)), i
+    # dense (all pairs) variant
+    m2, best2, _, _ = ctx.match_nn(A, B, mode=pkg.MATCH_PLAIN)
+    D = ctx.dist_matrix(A, B)
+    assert np.array_equal(m2, D.argmin(1)) and np.array_equal(best2, D.min(1))
+
+
+@pytest.mark.parametrize("n,window", [(60, 0), (500, 0), (1024, 0), (300, 50), (1024, 50)])
+def test_search_for_initialization_vs_oracle(n, window, pkg, orc):
+    rng = np.random.default_rng(3 + n)
+    ctx = get_ctx(pkg, 640, 480)
+    cfg = orc.default_cfg(640, 480)
+    A, B, perm = make_pair(rng, n, noise=0.3)
+    # duplicates and near-duplicates so that claims and the ratio test both fire
+    B[5] = B[6]
+    A[10] = A[11]
+    pos1 = np.stack([rng.uniform(5, 634, n), rng.uniform(5, 474, n)], 1).astype(np.float32)
+    pos2 = np.empty_like(pos1)
+    pos2[:] = pos1[perm] + rng.uniform(-20, 20, (n, 2)).astype(np.float32)
+    cnt_o, m_o, prev_o = orc.search_for_initialization(cfg, 0.9, A, B, pos2, pos1, window)
+    cnt_g, m_g, prev_g = ctx.search_for_initialization(0.9, A, B, pos2, pos1, window)
+    assert cnt_g == cnt_o and np.array_equal(m_g, m_o) and np.array_equal(prev_g, prev_o)
+    assert cnt_o > n // 4
+
+
+def test_match_claims_force_fallback(pkg, orc):
+    """Many F1 rows share the same few nearest F2 rows, so the 8-entry lists run dry and the resolver has
+    to rescan rows; the result must still be the sequential one."""
+    rng = np.random.default_rng(9)
+    ctx = get_ctx(pkg, 640, 480)
+    cfg = orc.default_cfg(640, 480)
+    base = unit_rows(rng, 4)
+    A = np.repeat(base, 40, 0) + 0.02 * rng.normal(size=(160, 256)).astype(np.float32)
+    A = (A / np.linalg.norm(A, axis=1, keepdims=True)).astype(np.float32)
+    B = np.repeat(base, 30, 0) + 0.02 * rng.normal(size=(120, 256)).astype(np.float32)
+    B = (B / np.linalg.norm(B, axis=1, keepdims=True)).astype(np.float32)
+    pos = np.zeros((160, 2), np.float32)
+    pos2 = np.zeros((120, 2), np.float32)
+    cnt_o, m_o, _ = orc.search_for_initialization(cfg, 1.1, A, B, pos2, pos, 0)
+    cnt_g, m_g, _ = ctx.search_for_initialization(1.1, A, B, pos2, pos, 0)
+    assert cnt_g == cnt_o and np.array_equal(m_g, m_o)
+    assert cnt_o > 60
+
+
+def test_match_frames_resident(pkg, orc, synth):
+    H, W = 480, 640
+    ctx = get_ctx(pkg, W, H, 1024, batch=2)
+    imgs = [synth.make_frame(H, W, 11, t, "dense") for t in (0, 1)]
+    r = ctx.extract_batch(imgs)
+    cnt, m12 = ctx.match_frames(0, 1, r[0]["n"], 0.9)
+    cfg = orc.default_cfg(W, H, 1024)
+    cnt_o, m_o, _ = orc.search_for_initialization(cfg, 0.9, r[0]["desc"], r[1]["desc"], r[1]["un"], r[0]["un"], 0)
+    assert cnt == cnt_o and np.array_equal(m12, m_o)
+    assert cnt > 400
+
+
+def test_grid_matches_oracle(pkg, orc):
+    rng = np.random.default_rng(4)
+    ctx = get_ctx(pkg, 640, 480)
+    cfg = orc.default_cfg(640, 480)
+    pos = np.stack([rng.uniform(0, 640, 400), rng.uniform(0, 480, 400)], 1).astype(np.float32)
+    for _ in range(50):
+        x, y, r = float(rng.uniform(-20, 660)), float(rng.uniform(-20, 500)), float(rng.uniform(1, 80))
+        assert np.array_equal(ctx.features_in_area(pos, x, y, r), orc.features_in_area(cfg, pos, x, y, r))
+
+
+def random_map_graph(rng, desc, pos, m, n_medges):
+    n = desc.shape[0]
+    src = rng.choice(n, size=m, replace=False)
+    mdesc = desc[src] + 0.15 * rng.normal(size=(m, 256)).astype(np.float32) / 16
+    mdesc = (mdesc / np.linalg.norm(mdesc, axis=1, keepdims=True)).astype(np.float32)
+    inc = [[] for _ in range(m)]
+    for eid in range(n_medges):
+        a, b = rng.choice(m, size=2, replace=False)
+        inc[a].append((eid, int(b)))
+        inc[b].append((eid, int(a)))
+    ne = sum(len(i) for i in inc)
+    other = np.array([o for i in inc for _, o in i], np.int32)
+    other[rng.random(ne) < 0.05] = -1
+    g = dict(desc=mdesc, proj=(pos[src] + rng.uniform(-4, 4, (m, 2))).astype(np.float32),
+             viewcos=rng.uniform(0.99, 1.0, m).astype(np.float32), in_view=(rng.random(m) < 0.8).astype(np.uint8),
+             bad=(rng.random(m) < 0.05).astype(np.uint8), nobs=rng.integers(0, 3, m).astype(np.int32),
+             edge_off=np.cumsum([0] + [len(i) for i in inc]).astype(np.int32),
+             edge_id=np.array([e for i in inc for e, _ in i], np.int32), edge_other=other,
+             edge_ok=(rng.random(ne) < 0.9).astype(np.uint8))
+    return g
+
+
+def test_extend_map_matches_vs_oracle(pkg, orc, synth):
+    H, W = 480, 640
+    ctx = get_ctx(pkg, W, H)
+    cfg = orc.default_cfg(W, H)
+    r = ctx.extract(synth.make_frame(H, W, 1, 0, "sparse"))
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        m = 300
+        g = random_map_graph(rng, r["desc"], r["un"], m, 400)
+        tracked = (rng.random(m) < 0.05).astype(np.uint8)
+        fmp = np.full(r["n"], -1, np.int32)
+        pre = rng.choice(r["n"], size=30, replace=False)
+        fmp[pre] = rng.integers(0, m, 30)
+        fme = np.full(r["n_edges"], -1, np.int32)
+        args = (0.8, 3.0 + 2 * trial, g, r["desc"], r["un"], r["edge_idx"], r["conn_off"], r["conn_idx"], tracked, fmp, fme)
+        co, to, po, eo = orc.extend_map_matches(cfg, *args)
+        cg, tg, pg, eg = ctx.extend_map_matches(*args)
+        assert cg == co and np.array_equal(tg, to) and np.array_equal(pg, po) and np.array_equal(eg, eo)
+        assert co > 50 and (eo >= 0).sum() > 0
