@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Front-end throughput benchmark: frames/sec of extract + describe + match at 640x480.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One *step* = one pass of the whole front-end over one batch of independent camera streams
+(`--batch` frames, default 16, all resident in HBM before the timed region): the CNN stack, score map
++ NMS, line heat map + refine + line graph, descriptor sampling, and the all-pairs
+SearchForInitialization match of every stream's frame against its previous frame.  Streams are
+sharded over ranks (one process per GPU, weak scaling: every rank runs `--batch` streams); the only
+collective is the global-shutter barrier — an all-reduce(MIN) of the per-rank frame sequence number
+after every step.  Precision is fp32 operands with fp32 MFMA accumulation, the parity path.
+
+Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel measured
+with HIP events over the timed region, and a CPU baseline (the oracle port timed on this host).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_pkg  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def conv_macs(H, W):
+    """MACs per frame of every convolution, and of the ones run by conv_mfma_kernel<3,2,8>."""
+    h2, w2, h4, w4, h8, w8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+    layers = [  # (name, pixels, cin, cout, taps, dominant kernel?)
+        ("conv1a", H * W, 1, 64, 9, False), ("conv1b", H * W, 64, 64, 9, True),
+        ("conv2a", h2 * w2, 64, 64, 9, True), ("conv2b", h2 * w2, 64, 64, 9, True),
+        ("conv3a", h4 * w4, 64, 128, 9, True), ("conv3b", h4 * w4, 128, 128, 9, True),
+        ("conv4a", h8 * w8, 128, 128, 9, True), ("conv4b", h8 * w8, 128, 128, 9, True),
+        ("convPa", h8 * w8, 128, 256, 9, True), ("convPb", h8 * w8, 256, 65, 1, False),
+        ("convDa", h8 * w8, 128, 256, 9, True), ("convDb", h8 * w8, 256, 256, 1, False),
+        ("heat0", h8 * w8, 128, 256, 9, True), ("heat1", h4 * w4, 64, 64, 9, True),
+        ("heat2", h2 * w2, 16, 16, 9, False), ("heat3", H * W, 4, 2, 1, False)]
+    total = sum(p * ci * co * t for _, p, ci, co, t, _ in layers)
+    dom = sum(p * ci * co * t for _, p, ci, co, t, d in layers if d)
+    ndom = sum(1 for l in layers if l[5])
+    return total, dom, ndom
+
+
+def cpu_baseline(H, W, kind, max_num, seconds=12.0):
+    """The oracle (CPU port of the reference path) on this host: extract + match, frames/sec."""
+    from oracle import oracle as orc
+    synth = importlib.import_module("ppg_slam_amd.synth")
+    net = orc.Net()
+    cfg = orc.default_cfg(W, H, max_num)
+    scene = synth.make_scene(H, W, 11, kind)
+    prev = orc.extract(net, cfg, synth.frame_from_scene(scene, H, W, 0))
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cur = orc.extract(net, cfg, synth.frame_from_scene(scene, H, W, n + 1))
+        if prev["n"] and cur["n"]:
+            orc.search_for_initialization(cfg, 0.9, prev["desc"], cur["desc"], cur["un"], prev["un"], 0)
+        prev = cur
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds or n >= 64:
+            break
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} consecutive {W}x{H} '{kind}' frames, extract + all-pairs match vs previous frame; "
+                      f"conv stack OpenMP over {cores} threads, post-processing and matcher single-threaded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="independent camera streams per GPU per step")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--max-num", type=int, default=1024, help="JUNCTION_MAX_NUM (1024-keypoint match config)")
+    ap.add_argument("--kind", default="dense")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libppgfront has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = load_pkg()
+    synth = importlib.import_module("ppg_slam_amd.synth")
+    H, W, B = args.height, args.width, args.batch
+    ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=args.max_num, device_id=local_rank))
+
+    # B streams per rank; stream s of rank r is scene seed 1000*(r*B+s)+11; 8 consecutive frames of
+    # every stream are staged in HBM and replayed round-robin.
+    T = 8
+    host = np.empty((T, B, H, W), np.uint8)
+    for s in range(B):
+        scene = synth.make_scene(H, W, 1000 * (rank * B + s) + 11, args.kind)
+        for t in range(T):
+            host[t, s] = synth.frame_from_scene(scene, H, W, t)
+    frames = torch.from_numpy(host).cuda()
+    seq = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stats = {"kp": 0, "edges": 0, "matches": 0}
+
+    def submit(k):
+        ctx.submit_batch_device(frames[k % T].data_ptr(), B, match_prev=k > 0, nnratio=0.9)
+
+    def wait(k):
+        outs, cnts, _, n = ctx.wait_batch(to_dict=False, want_matches=True)
+        if dist is not None:  # global-shutter barrier: release frame group k on every GPU together
+            seq.fill_(k)
+            dist.all_reduce(seq, op=dist.ReduceOp.MIN)
+        stats["kp"] += sum(outs[b].n for b in range(n))
+        stats["edges"] += sum(outs[b].n_edges for b in range(n))
+        stats["matches"] += int(cnts.sum())
+
+    def run(first, count):
+        """`count` steps, software-pipelined two deep: the GPU works on batch k+1 while the host finishes k."""
+        submit(first)
+        for k in range(first + 1, first + count):
+            submit(k)
+            wait(k - 1)
+        wait(first + count - 1)
+
+    run(0, args.warmup + 1)  # +1: the very first batch has no previous frame to match
+    for key in stats:
+        stats[key] = 0
+    ctx.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.warmup + 1, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_macs, dom_macs, ndom = conv_macs(H, W)
+        dom_ms, dom_launches = prof["conv3x3"]
+        flops_per_launch = 2.0 * dom_macs * B / ndom          # algorithmic FLOPs of an average launch
+        avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
+        achieved = flops_per_launch / avg_launch_s / 1e12 if dom_launches else 0.0
+        frames_total = B * args.steps * world
+        out = {
+            "metric": "front-end frames/sec (extract+describe+match) @640x480",
+            "value": round(frames_total / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} synthetic '{args.kind}' scenes, {B} camera streams per GPU per step, "
+                                   f"full extract (CNN fp32 MFMA + NMS + line graph + descriptors, JUNCTION_MAX_NUM={args.max_num}) "
+                                   f"+ all-pairs SearchForInitialization match vs previous frame; input resident in HBM",
+                       "batch_per_gpu": B, "parallelism": f"stream-sharded x{world}, RCCL all-reduce(MIN) barrier per step",
+                       "avg_keypoints": round(stats["kp"] / (B * args.steps), 1),
+                       "avg_edges": round(stats["edges"] / (B * args.steps), 1),
+                       "avg_matches": round(stats["matches"] / (B * args.steps), 1)},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<3,2,8> (all 3x3 convolutions with >=64 couts)",
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(dom_launches),
+                         "flops_per_launch": flops_per_launch, "traffic": None},
+            "device_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+        }
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                tj = json.load(open(tr))
+                if tj.get("batch") == B and tj.get("width") == W and tj.get("height") == H:
+                    out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(H, W, args.kind, args.max_num)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,19 @@ int ppg_extract_batch(ppg_ctx* ctx, const uint8_t* const* imgs, int n, int row_s
 /* As ppg_extract_batch with the n images already resident in device memory, contiguous n*H*W bytes. */
 int ppg_extract_batch_device(ppg_ctx* ctx, const uint8_t* d_imgs, int n, ppg_frame_out* outs);
 
+/* Pipelined form for throughput: ppg_submit_batch_device enqueues the whole extract of n device-resident
+ * frames (and, with match_prev != 0, the all-pairs SearchForInitialization match of every frame b against
+ * frame b of the previously submitted batch) plus the copies to pinned host memory, and returns without
+ * waiting.  ppg_wait_batch blocks until the OLDEST submitted batch is on the host, finishes its line
+ * graphs and fills outs (and matches12: n rows of junction_max_num entries; n_matches: n counts; both
+ * optional).  It returns the batch's frame count (> 0) or a negative error.  At most two batches may be
+ * in flight; the buffers behind `outs` stay valid until the second submit after this wait.
+ * No counterpart in the reference (PPGExtractor::run blocks, PPGExtractor.cpp:125). */
+int ppg_submit_batch_device(ppg_ctx* ctx, const uint8_t* d_imgs, int n, int match_prev, float nnratio);
+/* The same for host images (copied to pinned staging memory before the call returns). */
+int ppg_submit_batch(ppg_ctx* ctx, const uint8_t* const* imgs, int n, int row_stride, int match_prev, float nnratio);
+int ppg_wait_batch(ppg_ctx* ctx, ppg_frame_out* outs, int32_t* matches12, int* n_matches);
+
 /* ---- the public pipeline stages of PPGExtractor (feature/include/PPGExtractor.h:56-65), exposed so
  * that each can be checked on its own.  They operate on the context's resident tensors for the
  * first n frames. ---- */
@@ -154,6 +167,12 @@ int ppg_search_for_initialization(ppg_ctx* ctx, float nnratio,
  * indices come back to the host. */
 int ppg_match_frames(ppg_ctx* ctx, int frame_a, int frame_b, float nnratio, int32_t* matches12, int* n_matches);
 
+/* The same for every stream of a batch: frame b of the PREVIOUS extract call (F1) against frame b of
+ * the LAST one (F2), b < n, all resident on the GPU.  matches12 holds n rows of junction_max_num
+ * entries (-1 beyond a frame's key-point count); n_matches (optional) holds n counts.  No counterpart in
+ * the reference, which matches one pair per call. */
+int ppg_match_prev_batch(ppg_ctx* ctx, int n, float nnratio, int32_t* matches12, int* n_matches);
+
 /* Frame::GetFeaturesInArea (map/src/Frame.cpp:262-315) over the 64x48 grid built as
  * Frame::AssignFeaturesToGrid / PosInGrid do (:138-156, :317-327) with the image bounds of
  * GeometricCamera::InitializeImageBounds (sensors/src/GeometricCamera.cpp:26-61).  Host-side integer
@@ -188,9 +207,25 @@ int ppg_extend_map_matches(ppg_ctx* ctx, float nnratio, float th, const ppg_mapg
                            const int32_t* conn_off, const uint32_t* conn_idx,
                            uint8_t* tracked, int32_t* frame_mp, int32_t* frame_me, int* n_matches);
 
-/* HIP stream the context launches on (as a void* hipStream_t) so that callers can time it with HIP
- * events, and per-stage device time of the last extract call in milliseconds. */
+/* HIP stream the context launches on (as a void* hipStream_t). */
 void* ppg_stream(ppg_ctx* ctx);
+
+/* Device-time accounting with HIP events recorded on that stream around every launch (no counterpart in
+ * the reference, which has no timers).  ppg_profile(ctx, 1) resets and enables, (ctx, 0) disables;
+ * ppg_profile_read returns accumulated milliseconds and the number of timed launches per class. */
+#define PPG_PROF_CONV3X3 0     /* conv_mfma_kernel<3,2,8>: every 3x3 convolution with >= 64 couts */
+#define PPG_PROF_CONV_OTHER 1  /* the 1x1 convolutions and the 16-cout 3x3 one */
+#define PPG_PROF_CONV1A 2
+#define PPG_PROF_POST 3        /* score map, NMS, heat map, refine, line candidates, descriptors */
+#define PPG_PROF_MATCH 4
+#define PPG_PROF_HOST_WAIT 5   /* host wall time blocked in hipStreamSynchronize inside ppg_collect */
+#define PPG_PROF_HOST_TAIL 6   /* host wall time of the order-dependent line-graph tail */
+#define PPG_PROF_HOST_SUBMIT 7 /* host wall time inside ppg_submit_batch* (launch + copy enqueue) */
+#define PPG_PROF_HOST_FINISH 8 /* host wall time inside ppg_wait_batch */
+#define PPG_PROF_HOST_TAIL_FRAMES 9 /* sum over frames of the per-frame tail time (launches = frames) */
+#define PPG_PROF_N 10
+int ppg_profile(ppg_ctx* ctx, int enable);
+int ppg_profile_read(ppg_ctx* ctx, double* ms, long long* launches);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,11 @@ def lib():
         L.ppg_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameOut)]
         L.ppg_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ppg_match_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int)]
+        L.ppg_match_prev_batch.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.ppg_submit_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.ppg_wait_batch.argtypes = [C.c_void_p, C.POINTER(FrameOut), C.c_void_p, C.c_void_p]
+        L.ppg_profile.argtypes = [C.c_void_p, C.c_int]
+        L.ppg_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -160,6 +165,31 @@ class Context:
         self._chk(self.L.ppg_extract_batch_device(C.c_void_p(self.h), C.c_void_p(dev_ptr), n, outs))
         return [_frame_to_dict(outs[i]) for i in range(n)] if to_dict else outs
 
+    def submit_batch_device(self, dev_ptr, n, match_prev=False, nnratio=0.9):
+        self._chk(self.L.ppg_submit_batch_device(C.c_void_p(self.h), C.c_void_p(dev_ptr), n, 1 if match_prev else 0,
+                                                 C.c_float(nnratio)))
+
+    def submit_batch(self, imgs, match_prev=False, nnratio=0.9):
+        n = len(imgs)
+        arrs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        for a in arrs:
+            if a.shape != (self.H, self.W):
+                raise ValueError("image shape mismatch")
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        self._chk(self.L.ppg_submit_batch(C.c_void_p(self.h), ptrs, n, self.W, 1 if match_prev else 0, C.c_float(nnratio)))
+
+    def wait_batch(self, to_dict=True, want_matches=True):
+        """Returns (frames, n_matches[n], matches12[n, max_num]) of the oldest submitted batch."""
+        B, M = int(self.cfg.max_batch), int(self.cfg.junction_max_num)
+        outs = (FrameOut * B)()
+        m12 = np.full((B, M), -1, np.int32) if want_matches else None
+        cnts = np.zeros(B, np.int32)
+        n = self.L.ppg_wait_batch(C.c_void_p(self.h), outs, _p(m12), _p(cnts))
+        if n <= 0:
+            self._chk(n if n < 0 else PPG_EINVAL)
+        frames = [_frame_to_dict(outs[i]) for i in range(n)] if to_dict else outs
+        return frames, cnts[:n], (m12[:n] if want_matches else None), n
+
     # ---- stages ----
     def inference(self, imgs):
         a = np.ascontiguousarray(np.stack(imgs), np.uint8)
@@ -239,6 +269,24 @@ class Context:
         cnt = C.c_int(0)
         self._chk(self.L.ppg_match_frames(C.c_void_p(self.h), fa, fb, C.c_float(nnratio), _p(m12), C.byref(cnt)))
         return cnt.value, m12[:n1]
+
+    def match_prev_batch(self, n, nnratio=0.9):
+        """Frame b of the previous extract call (F1) against frame b of the last one (F2), resident."""
+        M = int(self.cfg.junction_max_num)
+        m12 = np.full((n, M), -1, np.int32)
+        cnts = np.zeros(n, np.int32)
+        self._chk(self.L.ppg_match_prev_batch(C.c_void_p(self.h), n, C.c_float(nnratio), _p(m12), _p(cnts)))
+        return cnts, m12
+
+    def profile(self, enable=True):
+        self._chk(self.L.ppg_profile(C.c_void_p(self.h), 1 if enable else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 10)()
+        launches = (C.c_longlong * 10)()
+        self._chk(self.L.ppg_profile_read(C.c_void_p(self.h), ms, launches))
+        names = ("conv3x3", "conv_other", "conv1a", "post", "match", "host_wait", "host_tail", "host_submit", "host_finish", "host_tail_frames")
+        return {k: (ms[i], launches[i]) for i, k in enumerate(names)}
 
     def features_in_area(self, pos, x, y, r):
         pos = np.ascontiguousarray(pos, np.float32)

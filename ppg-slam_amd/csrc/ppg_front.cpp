@@ -7,6 +7,8 @@
 #include "ppg_kernels.h"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,11 +18,6 @@
 #include <map>
 #include <string>
 #include <vector>
-
-namespace ppg {
-hipError_t launch_dist_matrix_dev(const float* A, const int* nA_dev, int maxA, const float* B, const int* nB_dev, int maxB,
-                                  int dim, float* D, int ldd, hipStream_t s);
-}
 
 namespace {
 
@@ -49,6 +46,53 @@ struct FrameHost {
     std::vector<uint32_t> conn_idx, coline_pairs;
 };
 
+struct Cand {
+    uint32_t i, j;
+    float inlier, lscore_heat;
+    float dist;        // |Pj - Pi|                                   (:278-282)
+    float dir_ij;      // direction seen from i                        (:283)
+    float dir_ji;      // direction seen from j = dir_ij - pi, wrapped (:284-286)
+    bool bad;
+    float lscore;
+    float dir_from(uint32_t p) const { return p == i ? dir_ij : dir_ji; }
+    uint32_t other(uint32_t p) const { return p == i ? j : i; }
+};
+
+// Per-frame scratch that survives between calls so the tail allocates nothing in steady state.
+struct TailScratch {
+    std::vector<Cand> lines;
+    std::vector<std::vector<uint32_t>> conn;
+};
+
+// Everything a batch hands to the host lives twice, so that the GPU can work on batch k+1 while the host
+// finishes batch k (ppg_submit_batch_device / ppg_wait_batch).  The other slot also is "the previous
+// frame" of every stream for frame-to-frame matching.
+struct Slot {
+    // device
+    int* counters = nullptr;      // [B][8]: 0 resid, 1 kept, 2 line candidates, 3 key points
+    int32_t* kp_xy = nullptr;
+    float *kp_score = nullptr, *kp_un = nullptr, *desc = nullptr, *cand_sc = nullptr;
+    uint8_t* kp_out = nullptr;
+    uint32_t* cand_ij = nullptr;
+    int32_t* d_match = nullptr;   // [B][maxn]
+    int* d_mcounts = nullptr;     // [B]
+    // pinned host mirrors
+    int* h_counters = nullptr;
+    int32_t* h_kp_xy = nullptr;
+    float *h_kp_score = nullptr, *h_kp_un = nullptr, *h_desc = nullptr, *h_cand_sc = nullptr;
+    uint8_t* h_kp_out = nullptr;
+    uint32_t* h_cand_ij = nullptr;
+    int32_t* h_match = nullptr;
+    int* h_mcounts = nullptr;
+    uint8_t* h_img = nullptr;     // staging for host images
+    std::vector<FrameHost> frames;
+    std::vector<int> nkp;         // key points per frame, known after the slot was collected
+    hipEvent_t done = nullptr;    // recorded behind the slot's last device-to-host copy
+    int n = 0;                    // frames extracted into this slot
+    bool inflight = false;        // submitted, not yet waited for
+    bool matched = false;         // the submit included the match against the other slot
+};
+
 }  // namespace
 
 struct ppg_ctx {
@@ -56,7 +100,7 @@ struct ppg_ctx {
     std::string weights_path;
     std::string err;
     int W = 0, H = 0, w8 = 0, h8 = 0, B = 0, maxn = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     std::vector<void*> dev_allocs, host_allocs;
     // weights
     DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
@@ -76,6 +120,7 @@ struct ppg_ctx {
     uint8_t* kp_out = nullptr;
     uint32_t* cand_ij = nullptr;
     float* cand_sc = nullptr;
+    int* row_cnt = nullptr;
     // pinned host mirrors
     uint8_t* h_img = nullptr;
     int* h_counters = nullptr;
@@ -83,9 +128,24 @@ struct ppg_ctx {
     float *h_kp_score = nullptr, *h_kp_un = nullptr, *h_desc = nullptr, *h_cand_sc = nullptr;
     uint8_t* h_kp_out = nullptr;
     uint32_t* h_cand_ij = nullptr;
-    std::vector<FrameHost> frames;
+    std::vector<FrameHost>* frames = nullptr;
+    Slot slot[2];
+    int cur = 0;  // slot the alias pointers above refer to
+    std::vector<TailScratch> tails;
+    int host_threads = 1;
     bool skip_score = false, skip_refine = false;
     int last_n = 0;
+    // previous extract call's descriptors / counts stay resident for frame-to-frame matching
+    float* desc_prev = nullptr;
+    int* counters_prev = nullptr;
+    int32_t* d_match = nullptr;
+    int* d_mcounts = nullptr;
+    // optional per-kernel-class timing with HIP events on the context's stream
+    bool prof = false;
+    std::vector<hipEvent_t> ev_all, ev_free;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pairs;
+    double prof_ms[PPG_PROF_N] = {};
+    long long prof_launches[PPG_PROF_N] = {};
     // matcher scratch (grown on demand)
     DBuf<float> mA, mB, mD, mBest, mSecond, mTopD;
     DBuf<int32_t> mOff, mIdx, mMatch, mTopI;
@@ -93,7 +153,8 @@ struct ppg_ctx {
     DBuf<uint32_t> mClaim;
     int* mCount = nullptr;
     int* h_mcount = nullptr;
-    int32_t* h_match = nullptr;  // pinned, maxn
+    int* h_mcounts = nullptr;    // alias of the current slot's
+    int32_t* h_match = nullptr;  // alias of the current slot's
 };
 
 namespace {
@@ -114,6 +175,70 @@ int fail(ppg_ctx* c, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                      \
         if (e_ != hipSuccess) return fail((c), PPG_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+hipEvent_t prof_event(ppg_ctx* c) {
+    if (c->ev_free.empty()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_all.push_back(e);
+        return e;
+    }
+    hipEvent_t e = c->ev_free.back();
+    c->ev_free.pop_back();
+    return e;
+}
+
+// Times what is enqueued on the context's stream between construction and destruction.
+struct ProfScope {
+    ppg_ctx* c;
+    int cls;
+    hipEvent_t e0 = nullptr;
+    ProfScope(ppg_ctx* ctx, int k) : c(ctx), cls(k) {
+        if (c->prof && (e0 = prof_event(c))) (void)hipEventRecord(e0, c->stream);
+    }
+    ~ProfScope() {
+        if (!e0) return;
+        hipEvent_t e1 = prof_event(c);
+        if (!e1) { c->ev_free.push_back(e0); return; }
+        (void)hipEventRecord(e1, c->stream);
+        c->ev_pairs.push_back({cls, {e0, e1}});
+    }
+};
+
+// Accumulates every timed span whose closing event has completed; later spans stay queued.
+void prof_resolve(ppg_ctx* c) {
+    size_t keep = 0;
+    for (size_t k = 0; k < c->ev_pairs.size(); k++) {
+        auto p = c->ev_pairs[k];
+        float ms = 0.f;
+        if (hipEventQuery(p.second.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            c->prof_ms[p.first] += ms;
+            c->prof_launches[p.first] += 1;
+            c->ev_free.push_back(p.second.first);
+            c->ev_free.push_back(p.second.second);
+        } else {
+            c->ev_pairs[keep++] = p;
+        }
+    }
+    c->ev_pairs.resize(keep);
+}
+
+void select_slot(ppg_ctx* c, int sidx) {
+    Slot& a = c->slot[sidx];
+    Slot& o = c->slot[sidx ^ 1];
+    c->cur = sidx;
+    c->counters = a.counters; c->kp_xy = a.kp_xy; c->kp_score = a.kp_score; c->kp_un = a.kp_un; c->kp_out = a.kp_out;
+    c->desc = a.desc; c->cand_ij = a.cand_ij; c->cand_sc = a.cand_sc; c->d_match = a.d_match; c->d_mcounts = a.d_mcounts;
+    c->h_counters = a.h_counters; c->h_kp_xy = a.h_kp_xy; c->h_kp_score = a.h_kp_score; c->h_kp_un = a.h_kp_un;
+    c->h_kp_out = a.h_kp_out; c->h_desc = a.h_desc; c->h_cand_ij = a.h_cand_ij; c->h_cand_sc = a.h_cand_sc;
+    c->h_match = a.h_match; c->h_mcounts = a.h_mcounts; c->frames = &a.frames; c->h_img = a.h_img;
+    c->desc_prev = o.desc; c->counters_prev = o.counters;
+}
 
 bool read_blob(const char* path, std::map<std::string, Tensor>& out, std::string& why) {
     FILE* f = fopen(path, "rb");
@@ -290,6 +415,7 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
     a.B = n; a.H = H; a.W = W; a.Cin = dc.cin; a.Cout = dc.cout;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.nblk = dc.nblk;
     a.mode = mode; a.relu = relu;
+    ProfScope ps(c, dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER);
     HIPCHK(c, ppg::launch_conv(a, dc.ks, dc.nt, c->stream));
     return PPG_OK;
 }
@@ -321,66 +447,57 @@ ppg::HeatArgs heat_args(ppg_ctx* c, int n) {
 // ---------------------------------------------------------------------------------------------
 const double kPi = 3.1415926535897932384626433832795, k2Pi = 6.283185307179586476925286766559;
 
-struct Cand {
-    uint32_t i, j;
-    float inlier, lscore_heat;
-    bool bad;
-    float lscore;
-};
-
-struct Geo {
-    const float* un;
-    float dist(uint32_t a, uint32_t b) const {  // :278-282 (symmetric by construction)
-        const uint32_t i = std::min(a, b), j = std::max(a, b);
-        const float vx = un[2 * j] - un[2 * i], vy = un[2 * j + 1] - un[2 * i + 1];
-        return std::sqrt(vx * vx + vy * vy);
-    }
-    float dir(uint32_t a, uint32_t b) const {  // :283-286
-        const uint32_t i = std::min(a, b), j = std::max(a, b);
-        float vx = un[2 * j] - un[2 * i], vy = un[2 * j + 1] - un[2 * i + 1];
-        const float d = std::sqrt(vx * vx + vy * vy);
-        vx = vx / d; vy = vy / d;
-        const float fwd = std::atan2(vy, vx);
-        if (a < b) return fwd;
-        float r = (float)(fwd - kPi);
-        if (r < -kPi) r = (float)(r + k2Pi);
-        return r;
-    }
-};
-
-void lines_tail(const ppg_config& cfg, int n, const float* un, std::vector<Cand>& cand, FrameHost& fh) {
-    Geo geo{un};
-    std::vector<std::vector<uint32_t>> conn(n);
-    std::vector<Cand> lines;  // candidateLines of the reference (survivors of the overlap test)
-    lines.reserve(cand.size());
-    auto overlap = [&](uint32_t a, uint32_t b) -> bool {  // :316-335 / :338-357
+void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* ij, const float* sc, int nc,
+                FrameHost& fh, TailScratch& ts) {
+    std::vector<Cand>& lines = ts.lines;  // candidateLines of the reference (survivors of the overlap test)
+    lines.clear();
+    if (ts.conn.size() < (size_t)n) ts.conn.resize(n);
+    std::vector<std::vector<uint32_t>>& conn = ts.conn;
+    for (int p = 0; p < n; p++) conn[p].clear();
+    auto overlap = [&](uint32_t a, float dirAB, float dNew) -> bool {  // :316-335 / :338-357
         bool isOverlap = false;
-        for (uint32_t lid : conn[a]) {
+        // Dead lines are skipped by the reference and never come back to life, so they are dropped
+        // from the incidence list while walking it (keeps the walk proportional to the live degree).
+        std::vector<uint32_t>& lst = conn[a];
+        size_t keep = 0;
+        for (size_t rd = 0; rd < lst.size(); rd++) {
+            const uint32_t lid = lst[rd];
             Cand& old = lines[lid];
             if (old.bad) continue;
-            const uint32_t pid_old = old.i == a ? old.j : old.i;
-            float ad = geo.dir(a, b) - geo.dir(a, pid_old);
+            lst[keep++] = lid;
+            float ad = dirAB - old.dir_from(a);
             if (ad < -kPi) ad = (float)(ad + k2Pi);
             if (ad > kPi) ad = (float)(ad - k2Pi);
             ad = std::fabs(ad);
             if (ad > 0.2 * kPi) continue;
-            const float dNew = geo.dist(a, b), dOld = geo.dist(a, pid_old);
+            const float dOld = old.dist;
             const float s = std::sin(ad);
             if (dNew <= dOld && dNew * s < cfg.line_dist_thresh) old.bad = true;
             if (dOld < dNew && dOld * s < cfg.line_dist_thresh) isOverlap = true;
         }
+        lst.resize(keep);
         return isOverlap;
     };
-    for (Cand& cd : cand) {
-        if (overlap(cd.i, cd.j)) continue;
-        if (overlap(cd.j, cd.i)) continue;
-        cd.bad = false;
+    for (int k = 0; k < nc; k++) {
+        Cand cd;
+        cd.i = ij[k] >> 16; cd.j = ij[k] & 0xFFFFu;
+        float vx = un[2 * cd.j] - un[2 * cd.i], vy = un[2 * cd.j + 1] - un[2 * cd.i + 1];
+        cd.dist = std::sqrt(vx * vx + vy * vy);
+        vx = vx / cd.dist; vy = vy / cd.dist;
+        cd.dir_ij = std::atan2(vy, vx);
+        float r = (float)(cd.dir_ij - kPi);
+        if (r < -kPi) r = (float)(r + k2Pi);
+        cd.dir_ji = r;
+        if (overlap(cd.i, cd.dir_ij, cd.dist)) continue;
+        if (overlap(cd.j, cd.dir_ji, cd.dist)) continue;
+        cd.inlier = sc[2 * k]; cd.lscore_heat = sc[2 * k + 1];
+        cd.bad = false; cd.lscore = 0.f;
         lines.push_back(cd);
         const uint32_t lid = (uint32_t)lines.size() - 1;
         conn[cd.i].push_back(lid);
         conn[cd.j].push_back(lid);
     }
-    for (auto& v : conn) v.clear();
+    for (int p = 0; p < n; p++) conn[p].clear();
     for (uint32_t k = 0; k < lines.size(); k++) {  // :367-389
         Cand& kl = lines[k];
         if (kl.bad) continue;
@@ -392,9 +509,11 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, std::vector<Cand>
     }
     fh.coline_off.assign(n + 1, 0);
     fh.coline_pairs.clear();
+    std::vector<uint32_t> idx;
     for (int p = 0; p < n; p++) {  // :392-432
         fh.coline_off[p] = (int32_t)(fh.coline_pairs.size() / 2);
-        std::vector<uint32_t> idx = conn[p];
+        if (conn[p].size() < 2) continue;
+        idx = conn[p];
         while (idx.size() > 1) {
             double minDiff = 1e9;
             int b1 = -1, b2 = -1, bestId = -1;
@@ -403,10 +522,9 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, std::vector<Cand>
             for (uint32_t q = 0; q + 1 < idx.size(); q++) {
                 const Cand& kl2 = lines[idx[q]];
                 if (kl2.bad) continue;
-                const uint32_t p1 = kl1.i == (uint32_t)p ? kl1.j : kl1.i, p2 = kl2.i == (uint32_t)p ? kl2.j : kl2.i;
-                const float ad = geo.dir(p, p1) - geo.dir(p, p2);
-                const double pd = 0.5 * (geo.dist(p, p1) + geo.dist(p, p2)) * std::fabs(std::sin(ad));
-                if (minDiff > pd) { minDiff = pd; bestId = (int)q; b1 = (int)p1; b2 = (int)p2; }
+                const float ad = kl1.dir_from(p) - kl2.dir_from(p);
+                const double pd = 0.5 * (kl1.dist + kl2.dist) * std::fabs(std::sin(ad));
+                if (minDiff > pd) { minDiff = pd; bestId = (int)q; b1 = (int)kl1.other(p); b2 = (int)kl2.other(p); }
             }
             if (minDiff > cfg.line_dist_thresh) { idx.pop_back(); continue; }
             fh.coline_pairs.push_back((uint32_t)b1);
@@ -419,21 +537,21 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, std::vector<Cand>
     fh.coline_off[n] = (int32_t)(fh.coline_pairs.size() / 2);
     fh.edge_idx.clear();
     fh.edge_score.clear();
-    std::vector<std::vector<uint32_t>> oc(n);
+    for (int p = 0; p < n; p++) conn[p].clear();
     for (const Cand& cl : lines) {  // :433-441
         if (cl.bad) continue;
         const uint32_t e = (uint32_t)fh.edge_score.size();
         fh.edge_idx.push_back(cl.i);
         fh.edge_idx.push_back(cl.j);
         fh.edge_score.push_back(cl.lscore);
-        oc[cl.i].push_back(e);
-        oc[cl.j].push_back(e);
+        conn[cl.i].push_back(e);
+        conn[cl.j].push_back(e);
     }
     fh.conn_off.assign(n + 1, 0);
     fh.conn_idx.clear();
     for (int p = 0; p < n; p++) {
         fh.conn_off[p] = (int32_t)fh.conn_idx.size();
-        for (uint32_t e : oc[p]) fh.conn_idx.push_back(e);
+        for (uint32_t e : conn[p]) fh.conn_idx.push_back(e);
     }
     fh.conn_off[n] = (int32_t)fh.conn_idx.size();
 }
@@ -495,7 +613,11 @@ void ppg_destroy(ppg_ctx* c) {
                   c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p};
     for (void* p : ms)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev_all) (void)hipEventDestroy(e);
+    for (Slot& sl : c->slot)
+        if (sl.done) (void)hipEventDestroy(sl.done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
 
@@ -524,6 +646,7 @@ static int create_impl(ppg_ctx* c) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, PPG_EHIP, "device %d is %s; this library is built for gfx950 only", f.device_id, prop.gcnArchName);
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     int rc = load_weights(c);
     if (rc) return rc;
     const size_t B = c->B, HW = (size_t)c->H * c->W, hw = (size_t)c->h8 * c->w8;
@@ -553,33 +676,53 @@ static int create_impl(ppg_ctx* c) {
     c->resid_cap = (int)HW;
     c->kept_cap = (int)(HW / 16 + 64);
     c->cand_cap = std::max(1, c->maxn * (c->maxn - 1) / 2);
-    c->cand_fast = std::min(c->cand_cap, 8192);
+    c->cand_fast = std::min(c->cand_cap, 32768);
     DA(resid, B * c->resid_cap);
     DA(kept, B * c->kept_cap);
     DA(kept_key, B * c->kept_cap);
-    DA(counters, B * 8);
-    DA(kp_xy, B * c->maxn * 2);
-    DA(kp_score, B * c->maxn);
-    DA(kp_un, B * c->maxn * 2);
-    DA(kp_out, B * c->maxn);
-    DA(desc, B * c->maxn * 256);
-    DA(cand_ij, B * c->cand_cap);
-    DA(cand_sc, B * c->cand_cap * 2);
+    DA(row_cnt, B * (c->maxn + 1));
     DA(mCount, 4);
-    HA(h_img, B * HW);
-    HA(h_counters, B * 8);
-    HA(h_kp_xy, B * c->maxn * 2);
-    HA(h_kp_score, B * c->maxn);
-    HA(h_kp_un, B * c->maxn * 2);
-    HA(h_kp_out, B * c->maxn);
-    HA(h_desc, B * c->maxn * 256);
-    HA(h_cand_ij, B * c->cand_cap);
-    HA(h_cand_sc, B * c->cand_cap * 2);
     HA(h_mcount, 4);
-    HA(h_match, (size_t)c->maxn);
+    for (Slot& sl : c->slot) {
+#define DS(ptr, n) do { rc = dalloc(c, &sl.ptr, (n)); if (rc) return rc; } while (0)
+#define HS(ptr, n) do { rc = halloc(c, &sl.ptr, (n)); if (rc) return rc; } while (0)
+        DS(counters, B * 8);
+        DS(kp_xy, B * c->maxn * 2);
+        DS(kp_score, B * c->maxn);
+        DS(kp_un, B * c->maxn * 2);
+        DS(kp_out, B * c->maxn);
+        DS(desc, B * c->maxn * 256);
+        DS(cand_ij, B * c->cand_cap);
+        DS(cand_sc, B * c->cand_cap * 2);
+        DS(d_match, B * c->maxn);
+        DS(d_mcounts, B);
+        HS(h_counters, B * 8);
+        HS(h_kp_xy, B * c->maxn * 2);
+        HS(h_kp_score, B * c->maxn);
+        HS(h_kp_un, B * c->maxn * 2);
+        HS(h_kp_out, B * c->maxn);
+        HS(h_desc, B * c->maxn * 256);
+        HS(h_cand_ij, B * c->cand_cap);
+        HS(h_cand_sc, B * c->cand_cap * 2);
+        HS(h_match, B * c->maxn);
+        HS(h_mcounts, B);
+        HS(h_img, B * HW);
+#undef DS
+#undef HS
+        HIPCHK(c, hipMemset(sl.counters, 0, sizeof(int) * 8 * B));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        sl.frames.resize(B);
+        sl.nkp.assign(B, 0);
+    }
 #undef DA
 #undef HA
-    c->frames.resize(B);
+    select_slot(c, 0);
+    c->tails.resize(B);
+    {
+        const char* e = getenv("PPG_HOST_THREADS");
+        int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        c->host_threads = std::max(1, std::min(t, 64));
+    }
     // warm-up on an all-ones image, as the reference constructor does (PPGExtractor.cpp:100-106)
     std::vector<uint8_t> warm(HW, 1);
     const uint8_t* wp = warm.data();
@@ -634,16 +777,28 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const size_t HW = (size_t)c->H * c->W;
     const uint8_t* dimg = imgs;
+    c->skip_score = c->skip_refine = false;
+    {
+        const int ns = c->cur ^ 1;
+        if (c->slot[ns].inflight) return fail(c, PPG_EINVAL, "two batches are in flight: call ppg_wait_batch first");
+        select_slot(c, ns);
+        c->slot[ns].n = n;
+        c->slot[ns].matched = false;
+        // nkp keeps the counts of the slot's last collected batch: a later ppg_wait_batch of the OTHER slot
+        // still needs them to size its match rows
+    }
     if (!on_device) {
-        if (imgs != c->h_img) memcpy(c->h_img, imgs, n * HW);
+        if (imgs != c->h_img) memcpy(c->h_img, imgs, n * HW);  // pinned staging buffer of this slot
         HIPCHK(c, hipMemcpyAsync(c->d_img, c->h_img, n * HW, hipMemcpyHostToDevice, c->stream));
         dimg = c->d_img;
     }
-    c->skip_score = c->skip_refine = false;
     const int H = c->H, W = c->W;
     ppg::Conv1aArgs a1;
     a1.img = dimg; a1.w = c->c1a_w; a1.bias = c->c1a_b; a1.out = c->a1; a1.B = n; a1.H = H; a1.W = W;
-    HIPCHK(c, ppg::launch_conv1a(a1, c->stream));
+    {
+        ProfScope ps(c, PPG_PROF_CONV1A);
+        HIPCHK(c, ppg::launch_conv1a(a1, c->stream));
+    }
     int rc;
 #define RC(x) do { rc = (x); if (rc) return rc; } while (0)
     // Backbone (net/Backbone.pt backbone.py:28-37)
@@ -661,8 +816,11 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     RC(run_conv(c, c->h0, c->feat, c->hs0, n, H / 8, W / 8, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h1, c->hs0, c->hs1, n, H / 4, W / 4, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h2, c->hs1, c->hs2, n, H / 2, W / 2, ppg::CONV_PS2, 1));
-    ppg::HeatArgs ha = heat_args(c, n);
-    HIPCHK(c, ppg::launch_heat_tail(ha, c->stream));
+    {
+        ProfScope ps(c, PPG_PROF_POST);
+        ppg::HeatArgs ha = heat_args(c, n);
+        HIPCHK(c, ppg::launch_heat_tail(ha, c->stream));
+    }
     // Descriptor (descriptor_decoder.py:14-15)
     RC(run_conv(c, c->da, c->feat, c->da_o, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
     RC(run_conv(c, c->db, c->da_o, c->descmap, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
@@ -675,6 +833,7 @@ int ppg_detect_keypoints(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    ProfScope ps(c, PPG_PROF_POST);
     HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(int) * 8 * n, c->stream));
     ppg::NmsArgs a = nms_args(c, n);
     if (!c->skip_score) HIPCHK(c, ppg::launch_score_map(a, c->stream));
@@ -688,11 +847,12 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     if (c->cfg.D[0] != 0.0f)
         return fail(c, PPG_EINVAL, "heat-map remap for D[0] != 0 (PPGExtractor.cpp:261-262) is not built");
+    ProfScope ps(c, PPG_PROF_POST);
     ppg::HeatArgs ha = heat_args(c, n);
     if (!c->skip_refine) HIPCHK(c, ppg::launch_refine(ha, c->stream));
     ppg::LineArgs la;
     la.heat = c->refined; la.kp_un = c->kp_un; la.kp_out = c->kp_out; la.counters = c->counters;
-    la.cand_ij = c->cand_ij; la.cand_sc = c->cand_sc; la.cand_cap = c->cand_cap;
+    la.row_cnt = c->row_cnt; la.cand_ij = c->cand_ij; la.cand_sc = c->cand_sc; la.cand_cap = c->cand_cap;
     la.B = n; la.H = c->H; la.W = c->W; la.max_num = c->maxn;
     la.heat_thresh = c->cfg.line_heatmap_thresh;
     la.inv_scale = 1.0f / std::sqrt((float)(c->H * c->H + c->W * c->W));  // PPGExtractor.cpp:74
@@ -704,6 +864,7 @@ int ppg_gen_descriptors(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    ProfScope ps(c, PPG_PROF_POST);
     ppg::DescArgs a;
     a.descmap = c->descmap; a.kp_xy = c->kp_xy; a.counters = c->counters; a.desc = c->desc;
     a.B = n; a.H = c->H; a.W = c->W; a.max_num = c->maxn;
@@ -711,71 +872,81 @@ int ppg_gen_descriptors(ppg_ctx* c, int n) {
     return PPG_OK;
 }
 
-int ppg_collect(ppg_ctx* c, int n, ppg_frame_out* outs) {
-    if (!c) return PPG_EINVAL;
-    if (n < 1 || n > c->B || !outs) return fail(c, PPG_EINVAL, "ppg_collect: bad argument");
-    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+// Device-to-host copies of everything the host needs from slot `si`, then the slot's done event.
+static int enqueue_d2h(ppg_ctx* c, int si, int n) {
+    Slot& sl = c->slot[si];
     const int M = c->maxn;
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->counters, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_kp_xy, c->kp_xy, sizeof(int32_t) * 2 * M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_kp_score, c->kp_score, sizeof(float) * M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_kp_un, c->kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_kp_out, c->kp_out, (size_t)M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_desc, c->desc, sizeof(float) * 256 * M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.counters, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_kp_xy, sl.kp_xy, sizeof(int32_t) * 2 * M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_kp_score, sl.kp_score, sizeof(float) * M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_kp_un, sl.kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_kp_out, sl.kp_out, (size_t)M * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_desc, sl.desc, sizeof(float) * 256 * M * n, hipMemcpyDeviceToHost, s));
     for (int b = 0; b < n; b++) {
-        HIPCHK(c, hipMemcpyAsync(c->h_cand_ij + (size_t)b * c->cand_cap, c->cand_ij + (size_t)b * c->cand_cap,
+        HIPCHK(c, hipMemcpyAsync(sl.h_cand_ij + (size_t)b * c->cand_cap, sl.cand_ij + (size_t)b * c->cand_cap,
                                  sizeof(uint32_t) * c->cand_fast, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_cand_sc + (size_t)b * c->cand_cap * 2, c->cand_sc + (size_t)b * c->cand_cap * 2,
+        HIPCHK(c, hipMemcpyAsync(sl.h_cand_sc + (size_t)b * c->cand_cap * 2, sl.cand_sc + (size_t)b * c->cand_cap * 2,
                                  sizeof(float) * 2 * c->cand_fast, hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (sl.matched) {
+        HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipEventRecord(sl.done, s));
+    return PPG_OK;
+}
+
+// Waits for slot `si`, runs the host tails of its frames and fills `outs`.
+static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
+    Slot& sl = c->slot[si];
+    const int M = c->maxn;
+    // the slot's data is complete once `done` fired; late copies use their own stream so that they do
+    // not queue behind the next batch already running on the main one
+    hipStream_t s = c->copy_stream;
+    const double t_sync0 = now_ms();
+    HIPCHK(c, hipEventSynchronize(sl.done));
+    if (c->prof) { c->prof_ms[PPG_PROF_HOST_WAIT] += now_ms() - t_sync0; c->prof_launches[PPG_PROF_HOST_WAIT] += 1; }
     bool more = false;
     for (int b = 0; b < n; b++) {
-        const int* cnt = c->h_counters + b * 8;
+        const int* cnt = sl.h_counters + b * 8;
         if (cnt[0] > c->resid_cap || cnt[1] > c->kept_cap || cnt[2] > c->cand_cap)
             return fail(c, PPG_ECAP, "frame %d: work list overflow (resid %d kept %d cand %d)", b, cnt[0], cnt[1], cnt[2]);
-        if (cnt[2] > c->cand_fast) {
+        if (cnt[2] > c->cand_fast) {  // rare: more line candidates than the fixed-size first copy holds
             more = true;
             const size_t o = (size_t)b * c->cand_cap + c->cand_fast;
             const size_t extra = (size_t)cnt[2] - c->cand_fast;
-            HIPCHK(c, hipMemcpyAsync(c->h_cand_ij + o, c->cand_ij + o, sizeof(uint32_t) * extra, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(c->h_cand_sc + 2 * o, c->cand_sc + 2 * o, sizeof(float) * 2 * extra, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_cand_ij + o, sl.cand_ij + o, sizeof(uint32_t) * extra, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_cand_sc + 2 * o, sl.cand_sc + 2 * o, sizeof(float) * 2 * extra, hipMemcpyDeviceToHost, s));
         }
     }
     if (more) HIPCHK(c, hipStreamSynchronize(s));
-    std::vector<Cand> cand;
-    std::vector<uint32_t> order;
-    for (int b = 0; b < n; b++) {
-        const int* cnt = c->h_counters + b * 8;
+    if (c->prof) prof_resolve(c);
+    for (int b = 0; b < n; b++) sl.nkp[b] = sl.h_counters[b * 8 + 3];
+    const double t_tail0 = now_ms();
+    std::vector<double> frame_ms(n, 0.0);
+    auto do_frame = [&](int b) {
+        const double tf0 = now_ms();
+        const int* cnt = sl.h_counters + b * 8;
         const int N = cnt[3], nc = cnt[2];
-        FrameHost& fh = c->frames[b];
+        FrameHost& fh = sl.frames[b];
         ppg_frame_out& o = outs[b];
         o.n = N;
-        o.kp_xy = c->h_kp_xy + (size_t)b * M * 2;
-        o.kp_score = c->h_kp_score + (size_t)b * M;
-        o.kp_un = c->h_kp_un + (size_t)b * M * 2;
-        o.kp_out = c->h_kp_out + (size_t)b * M;
-        o.desc = c->h_desc + (size_t)b * M * 256;
+        o.kp_xy = sl.h_kp_xy + (size_t)b * M * 2;
+        o.kp_score = sl.h_kp_score + (size_t)b * M;
+        o.kp_un = sl.h_kp_un + (size_t)b * M * 2;
+        o.kp_out = sl.h_kp_out + (size_t)b * M;
+        o.desc = sl.h_desc + (size_t)b * M * 256;
         if (N == 0) {
             // PPGExtractor.cpp:239-240 returns before touching mvKeyEdges (stale edges of the previous
             // frame stay in the reference's member); with no key points they index nothing, so this
             // boundary reports an empty graph.
-            fh = FrameHost();
+            fh.edge_idx.clear(); fh.edge_score.clear(); fh.conn_idx.clear(); fh.coline_pairs.clear();
             fh.conn_off.assign(1, 0);
             fh.coline_off.assign(1, 0);
         } else {
-            const uint32_t* ij = c->h_cand_ij + (size_t)b * c->cand_cap;
-            const float* sc = c->h_cand_sc + (size_t)b * c->cand_cap * 2;
-            order.resize(nc);
-            for (int k = 0; k < nc; k++) order[k] = k;
-            std::sort(order.begin(), order.end(), [ij](uint32_t x, uint32_t y) { return ij[x] < ij[y]; });
-            cand.resize(nc);
-            for (int k = 0; k < nc; k++) {
-                const uint32_t q = order[k];
-                cand[k] = Cand{ij[q] >> 16, ij[q] & 0xFFFFu, sc[2 * q], sc[2 * q + 1], false, 0.f};
-            }
-            lines_tail(c->cfg, N, o.kp_un, cand, fh);
+            lines_tail(c->cfg, N, o.kp_un, sl.h_cand_ij + (size_t)b * c->cand_cap,
+                       sl.h_cand_sc + (size_t)b * c->cand_cap * 2, nc, fh, c->tails[b]);
         }
         o.n_edges = (int)fh.edge_score.size();
         o.edge_idx = fh.edge_idx.data();
@@ -784,29 +955,147 @@ int ppg_collect(ppg_ctx* c, int n, ppg_frame_out* outs) {
         o.conn_idx = fh.conn_idx.data();
         o.coline_off = fh.coline_off.data();
         o.coline_pairs = fh.coline_pairs.data();
+        frame_ms[b] = now_ms() - tf0;
+    };
+    // frames are independent: spread the order-dependent tails over host threads
+    const int nthreads = std::max(1, std::min(n, c->host_threads));
+    if (nthreads == 1) {
+        for (int b = 0; b < n; b++) do_frame(b);
+    } else {
+        std::vector<std::thread> pool;
+        pool.reserve(nthreads - 1);
+        for (int t = 1; t < nthreads; t++)
+            pool.emplace_back([&, t]() { for (int b = t; b < n; b += nthreads) do_frame(b); });
+        for (int b = 0; b < n; b += nthreads) do_frame(b);
+        for (auto& th : pool) th.join();
+    }
+    if (c->prof) {
+        c->prof_ms[PPG_PROF_HOST_TAIL] += now_ms() - t_tail0;
+        c->prof_launches[PPG_PROF_HOST_TAIL] += 1;
+        for (int b = 0; b < n; b++) c->prof_ms[PPG_PROF_HOST_TAIL_FRAMES] += frame_ms[b];
+        c->prof_launches[PPG_PROF_HOST_TAIL_FRAMES] += n;
     }
     return PPG_OK;
 }
 
-static int extract_common(ppg_ctx* c, const uint8_t* imgs, int n, int on_device, ppg_frame_out* outs) {
+int ppg_collect(ppg_ctx* c, int n, ppg_frame_out* outs) {
+    if (!c) return PPG_EINVAL;
+    if (n < 1 || n > c->B || !outs) return fail(c, PPG_EINVAL, "ppg_collect: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    int rc = enqueue_d2h(c, c->cur, n);
+    if (!rc) rc = finish_slot(c, c->cur, n, outs);
+    return rc;
+}
+
+static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const float* dB, const int* nB, int batch,
+                          float nnratio, int32_t* d_match, int* d_mcounts);
+
+static int enqueue_extract(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     int rc = ppg_inference(c, imgs, n, on_device);
     if (!rc) rc = ppg_detect_keypoints(c, n);
     if (!rc) rc = ppg_detect_lines(c, n);
     if (!rc) rc = ppg_gen_descriptors(c, n);
+    return rc;
+}
+
+static int extract_common(ppg_ctx* c, const uint8_t* imgs, int n, int on_device, ppg_frame_out* outs) {
+    if (c->slot[0].inflight || c->slot[1].inflight)
+        return fail(c, PPG_EINVAL, "a submitted batch is pending: call ppg_wait_batch first");
+    int rc = enqueue_extract(c, imgs, n, on_device);
     if (!rc) rc = ppg_collect(c, n, outs);
     return rc;
 }
 
-int ppg_extract_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, ppg_frame_out* outs) {
+static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, const uint8_t** staged);
+
+static int submit_common(ppg_ctx* c, const uint8_t* imgs, int n, int on_device, int match_prev, float nnratio) {
+    const double t0 = now_ms();
+    if (match_prev && c->slot[c->cur].n < n)
+        return fail(c, PPG_EINVAL, "match_prev needs a previous batch of at least %d frames", n);
+    int rc = enqueue_extract(c, imgs, n, on_device);  // switches to the other slot or fails if it is in flight
+    if (rc) return rc;
+    Slot& sl = c->slot[c->cur];
+    if (match_prev) {
+        rc = match_resident(c, c->desc_prev, c->counters_prev + 3, c->desc, c->counters + 3, n, nnratio, sl.d_match, sl.d_mcounts);
+        if (rc) return rc;
+        sl.matched = true;
+    }
+    rc = enqueue_d2h(c, c->cur, n);
+    if (rc) return rc;
+    sl.inflight = true;
+    if (c->prof) { c->prof_ms[PPG_PROF_HOST_SUBMIT] += now_ms() - t0; c->prof_launches[PPG_PROF_HOST_SUBMIT] += 1; }
+    return PPG_OK;
+}
+
+int ppg_submit_batch_device(ppg_ctx* c, const uint8_t* d_imgs, int n, int match_prev, float nnratio) {
     if (!c) return PPG_EINVAL;
-    if (!imgs || !outs || n < 1 || n > c->B || row_stride < c->W)
-        return fail(c, PPG_EINVAL, "ppg_extract_batch: bad argument (n = %d, max_batch = %d)", n, c->B);
+    if (!d_imgs || n < 1 || n > c->B) return fail(c, PPG_EINVAL, "ppg_submit_batch_device: bad argument");
+    return submit_common(c, d_imgs, n, 1, match_prev, nnratio);
+}
+
+int ppg_submit_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, int match_prev, float nnratio) {
+    if (!c) return PPG_EINVAL;
+    const uint8_t* staged = nullptr;
+    int rc = stage_host_images(c, imgs, n, row_stride, &staged);
+    if (rc) return rc;
+    return submit_common(c, staged, n, 0, match_prev, nnratio);
+}
+
+int ppg_wait_batch(ppg_ctx* c, ppg_frame_out* outs, int32_t* m12, int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (!outs) return fail(c, PPG_EINVAL, "ppg_wait_batch: outs is NULL");
+    // slots alternate, so the older pending batch is the one that is not current (if it is pending)
+    int si = c->cur ^ 1;
+    if (!c->slot[si].inflight) si = c->cur;
+    Slot& sl = c->slot[si];
+    if (!sl.inflight) return fail(c, PPG_EINVAL, "ppg_wait_batch: nothing was submitted");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int n = sl.n, M = c->maxn;
+    const double t0 = now_ms();
+    int rc = finish_slot(c, si, n, outs);
+    sl.inflight = false;
+    if (rc) return rc;
+    if (c->prof) { c->prof_ms[PPG_PROF_HOST_FINISH] += now_ms() - t0; c->prof_launches[PPG_PROF_HOST_FINISH] += 1; }
+    if (sl.matched) {
+        const Slot& prev = c->slot[si ^ 1];
+        for (int b = 0; b < n; b++) {
+            if (m12) {
+                memcpy(m12 + (size_t)b * M, sl.h_match + (size_t)b * M, sizeof(int32_t) * prev.nkp[b]);
+                for (int k = prev.nkp[b]; k < M; k++) m12[(size_t)b * M + k] = -1;
+            }
+            if (n_matches) n_matches[b] = sl.h_mcounts[b];
+        }
+    } else {
+        if (m12) for (size_t k = 0; k < (size_t)n * M; k++) m12[k] = -1;
+        if (n_matches) for (int b = 0; b < n; b++) n_matches[b] = 0;
+    }
+    return n;
+}
+
+// copies n host images (row_stride >= W) into the pinned staging buffer of the slot the next extract uses
+static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, const uint8_t** staged) {
+    if (!imgs || n < 1 || n > c->B || row_stride < c->W)
+        return fail(c, PPG_EINVAL, "bad image batch (n = %d, max_batch = %d, row_stride = %d)", n, c->B, row_stride);
+    Slot& nx = c->slot[c->cur ^ 1];
+    if (nx.inflight) return fail(c, PPG_EINVAL, "two batches are in flight: call ppg_wait_batch first");
     const size_t HW = (size_t)c->H * c->W;
     for (int b = 0; b < n; b++) {
         if (!imgs[b]) return fail(c, PPG_EINVAL, "image %d is NULL", b);
-        for (int y = 0; y < c->H; y++) memcpy(c->h_img + b * HW + (size_t)y * c->W, imgs[b] + (size_t)y * row_stride, c->W);
+        for (int y = 0; y < c->H; y++) memcpy(nx.h_img + b * HW + (size_t)y * c->W, imgs[b] + (size_t)y * row_stride, c->W);
     }
-    return extract_common(c, c->h_img, n, 0, outs);
+    *staged = nx.h_img;
+    return PPG_OK;
+}
+
+int ppg_extract_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, ppg_frame_out* outs) {
+    if (!c) return PPG_EINVAL;
+    if (!outs) return fail(c, PPG_EINVAL, "ppg_extract_batch: outs is NULL");
+    if (c->slot[0].inflight || c->slot[1].inflight)
+        return fail(c, PPG_EINVAL, "a submitted batch is pending: call ppg_wait_batch first");
+    const uint8_t* staged = nullptr;
+    int rc = stage_host_images(c, imgs, n, row_stride, &staged);
+    if (rc) return rc;
+    return extract_common(c, staged, n, 0, outs);
 }
 
 int ppg_extract(ppg_ctx* c, const uint8_t* img, int row_stride, ppg_frame_out* out) {
@@ -870,7 +1159,6 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     if (!rc) rc = grow(c, c->mSecond, nA);
     if (!rc) rc = grow(c, c->mTopD, (size_t)nA * 8 + 64);
     if (!rc) rc = grow(c, c->mTopI, (size_t)nA * 8 + 64);
-    if (!rc) rc = grow(c, c->mClaim, 2048);
     if (!rc && csr) rc = grow(c, c->mOff, (size_t)nA + 1);
     if (!rc && csr) rc = grow(c, c->mIdx, std::max<size_t>(nd, 1));
     if (!rc && skipB) rc = grow(c, c->mSkip, std::max(nB, 1));
@@ -888,7 +1176,7 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     ppg::MatchArgs m;
     m.D = c->mD.p; m.ldd = csr ? 0 : nB; m.cand_off = csr ? c->mOff.p : nullptr; m.cand_idx = csr ? c->mIdx.p : nullptr;
     m.skipB = skipB ? c->mSkip.p : nullptr; m.nA_dev = nullptr; m.nB_dev = nullptr; m.nA = nA; m.nB = nB;
-    m.th = th; m.ratio = ratio; m.topk_idx = c->mTopI.p; m.topk_dist = c->mTopD.p; m.claimed = c->mClaim.p;
+    m.th = th; m.ratio = ratio; m.topk_idx = c->mTopI.p; m.topk_dist = c->mTopD.p; m.claimed = nullptr;
     m.match12 = c->mMatch.p; m.best = c->mBest.p; m.second = c->mSecond.p; m.n_matches = c->mCount;
     if (!csr && nB == 0) {
         // no candidates at all: every row is unmatched
@@ -1029,37 +1317,82 @@ int ppg_search_for_initialization(ppg_ctx* c, float nnratio, const float* desc1,
     return PPG_OK;
 }
 
+static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const float* dB, const int* nB, int batch,
+                          float nnratio, int32_t* d_match, int* d_mcounts) {
+    const int M = c->maxn;
+    int rc = grow(c, c->mD, (size_t)M * M * batch);
+    if (!rc) rc = grow(c, c->mBest, (size_t)M * batch);
+    if (!rc) rc = grow(c, c->mSecond, (size_t)M * batch);
+    if (!rc) rc = grow(c, c->mTopD, (size_t)M * 8 * batch + 64);
+    if (!rc) rc = grow(c, c->mTopI, (size_t)M * 8 * batch + 64);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    ProfScope ps(c, PPG_PROF_MATCH);
+    HIPCHK(c, ppg::launch_dist_matrix_batched(dA, nA, M, (size_t)M * 256, dB, nB, M, (size_t)M * 256, 256, c->mD.p, M,
+                                              (size_t)M * M, 8, batch, s));
+    ppg::MatchArgs m;
+    m.D = c->mD.p; m.ldd = M; m.cand_off = nullptr; m.cand_idx = nullptr; m.skipB = nullptr;
+    m.nA_dev = nA; m.nB_dev = nB; m.nA = M; m.nB = M; m.th = 0.7f /* TH_LOW, Matcher.cpp:13 */; m.ratio = nnratio;
+    m.topk_idx = c->mTopI.p; m.topk_dist = c->mTopD.p; m.claimed = nullptr;
+    m.match12 = d_match; m.best = c->mBest.p; m.second = c->mSecond.p; m.n_matches = d_mcounts;
+    m.batch = batch; m.bs_D = (size_t)M * M; m.bs_rows = M; m.bs_n = 8;
+    HIPCHK(c, ppg::launch_match_init(m, s));
+    return PPG_OK;
+}
+
 int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, int* n_matches) {
     if (!c) return PPG_EINVAL;
-    if (fa < 0 || fb < 0 || fa >= c->last_n || fb >= c->last_n || !m12)
+    Slot& sl = c->slot[c->cur];
+    if (sl.inflight || c->slot[c->cur ^ 1].inflight) return fail(c, PPG_EINVAL, "a submitted batch is pending");
+    if (fa < 0 || fb < 0 || fa >= sl.n || fb >= sl.n || !m12)
         return fail(c, PPG_EINVAL, "ppg_match_frames: frames must be in the last extracted batch");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int M = c->maxn;
-    int rc = grow(c, c->mD, (size_t)M * M);
-    if (!rc) rc = grow(c, c->mMatch, M);
-    if (!rc) rc = grow(c, c->mBest, M);
-    if (!rc) rc = grow(c, c->mSecond, M);
-    if (!rc) rc = grow(c, c->mTopD, (size_t)M * 8 + 64);
-    if (!rc) rc = grow(c, c->mTopI, (size_t)M * 8 + 64);
-    if (!rc) rc = grow(c, c->mClaim, 2048);
+    int rc = match_resident(c, c->desc + (size_t)fa * M * 256, c->counters + fa * 8 + 3, c->desc + (size_t)fb * M * 256,
+                            c->counters + fb * 8 + 3, 1, nnratio, sl.d_match, sl.d_mcounts);
     if (rc) return rc;
-    hipStream_t s = c->stream;
-    const int* nA = c->counters + fa * 8 + 3;
-    const int* nB = c->counters + fb * 8 + 3;
-    HIPCHK(c, ppg::launch_dist_matrix_dev(c->desc + (size_t)fa * M * 256, nA, M, c->desc + (size_t)fb * M * 256, nB, M, 256,
-                                          c->mD.p, M, s));
-    ppg::MatchArgs m;
-    m.D = c->mD.p; m.ldd = M; m.cand_off = nullptr; m.cand_idx = nullptr; m.skipB = nullptr;
-    m.nA_dev = nA; m.nB_dev = nB; m.nA = M; m.nB = M; m.th = 0.7f; m.ratio = nnratio;
-    m.topk_idx = c->mTopI.p; m.topk_dist = c->mTopD.p; m.claimed = c->mClaim.p;
-    m.match12 = c->mMatch.p; m.best = c->mBest.p; m.second = c->mSecond.p; m.n_matches = c->mCount;
-    HIPCHK(c, ppg::launch_match_init(m, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_match, c->mMatch.p, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_mcount, c->mCount, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const int n1 = c->h_counters[fa * 8 + 3];
-    memcpy(m12, c->h_match, sizeof(int32_t) * n1);
-    if (n_matches) *n_matches = c->h_mcount[0];
+    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->prof) prof_resolve(c);
+    memcpy(m12, sl.h_match, sizeof(int32_t) * sl.nkp[fa]);
+    if (n_matches) *n_matches = sl.h_mcounts[0];
+    return PPG_OK;
+}
+
+int ppg_match_prev_batch(ppg_ctx* c, int n, float nnratio, int32_t* m12, int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    Slot& sl = c->slot[c->cur];
+    const Slot& prev = c->slot[c->cur ^ 1];
+    if (sl.inflight || prev.inflight) return fail(c, PPG_EINVAL, "a submitted batch is pending");
+    if (n < 1 || n > sl.n || n > prev.n || !m12)
+        return fail(c, PPG_EINVAL, "ppg_match_prev_batch: needs two consecutive extract calls of >= n frames");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int M = c->maxn;
+    int rc = match_resident(c, c->desc_prev, c->counters_prev + 3, c->desc, c->counters + 3, n, nnratio, sl.d_match, sl.d_mcounts);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->prof) prof_resolve(c);
+    for (int b = 0; b < n; b++) {
+        memcpy(m12 + (size_t)b * M, sl.h_match + (size_t)b * M, sizeof(int32_t) * prev.nkp[b]);
+        for (int k = prev.nkp[b]; k < M; k++) m12[(size_t)b * M + k] = -1;
+        if (n_matches) n_matches[b] = sl.h_mcounts[b];
+    }
+    return PPG_OK;
+}
+
+int ppg_profile(ppg_ctx* c, int enable) {
+    if (!c) return PPG_EINVAL;
+    c->prof = enable != 0;
+    for (int k = 0; k < PPG_PROF_N; k++) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; }
+    return PPG_OK;
+}
+
+int ppg_profile_read(ppg_ctx* c, double* ms, long long* launches) {
+    if (!c || !ms || !launches) return PPG_EINVAL;
+    for (int k = 0; k < PPG_PROF_N; k++) { ms[k] = c->prof_ms[k]; launches[k] = c->prof_launches[k]; }
     return PPG_OK;
 }
 

@@ -82,7 +82,8 @@ struct LineArgs {
     const float* kp_un;   // [B][max_num][2]
     const uint8_t* kp_out;
     int* counters;        // [B][8]
-    uint32_t* cand_ij;    // [B][cand_cap] (i << 16 | j)
+    int* row_cnt;         // [B][max_num+1] work: survivors per row i, then their exclusive offsets
+    uint32_t* cand_ij;    // [B][cand_cap] (i << 16 | j), ascending
     float* cand_sc;       // [B][cand_cap][2] inlier rate, mean bilinear heat
     int cand_cap;
     int B, H, W, max_num;
@@ -104,6 +105,10 @@ hipError_t launch_desc_sample(const DescArgs& a, hipStream_t s);
 // ---- descriptor matching ----
 // D[i*ldd + j] = ||A[i] - B[j]||, dim 256 (multiple of 16)
 hipError_t launch_dist_matrix(const float* A, int nA, const float* B, int nB, int dim, float* D, int ldd, hipStream_t s);
+// batched over blockIdx.z: A + b*sA, B + b*sB, D + b*sD, row counts nA_dev[b*sn], nB_dev[b*sn]
+hipError_t launch_dist_matrix_batched(const float* A, const int* nA_dev, int maxA, size_t sA, const float* B,
+                                      const int* nB_dev, int maxB, size_t sB, int dim, float* D, int ldd, size_t sD,
+                                      int sn, int batch, hipStream_t s);
 // distances for CSR candidate lists: Dc[cand_off[i] + k] = ||A[i] - B[cand_idx[cand_off[i]+k]]||
 hipError_t launch_dist_csr(const float* A, int nA, const float* B, int dim, const int32_t* cand_off,
                            const int32_t* cand_idx, float* Dc, hipStream_t s);
@@ -125,6 +130,11 @@ struct MatchArgs {
     float* best;               // [nA]
     float* second;             // [nA]
     int* n_matches;            // device int
+    // batched launch over independent problems (dense mode only): problem b = blockIdx.y uses
+    // D + b*bs_D, per-row arrays + b*bs_rows (top-k lists x8), counts nA_dev[b*bs_n], n_matches[b]
+    int batch = 1;
+    size_t bs_D = 0, bs_rows = 0;
+    int bs_n = 0;
 };
 hipError_t launch_match_plain(const MatchArgs& a, hipStream_t s);
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s);

@@ -660,34 +660,91 @@ hipError_t launch_refine(const HeatArgs& a, hipStream_t s) {
 
 // =====================================================================================
 // detectLines, state-independent part (feature/src/PPGExtractor.cpp:290-313 and :367-389).
-// For every in-image pair i < j: the three-point heat probe (:304-313).  Survivors are appended
-// (unordered) with the two scores the reference computes later for lines that are still alive
+// For every in-image pair i < j: the three-point heat probe (:304-313).  Survivors are listed in
+// (i, j) order with the two scores the reference computes later for lines that are still alive
 // (heatMapInlierRate :484-497, heatMapLineScore :502-512); both depend only on the end points, so
 // they can be evaluated up front.  The order-dependent overlap / collinearity logic consumes this
-// list on the host after sorting it by (i, j).
+// list on the host.
 // =====================================================================================
 __constant__ float kInvSampleGap[4] = {0.3333f, 0.200f, 0.1427f, 0.1111f};  // PPGExtractor.cpp:19
 
 __device__ inline float heat_at(const float* heat, int W, int y, int x) { return heat[(size_t)y * W + x]; }
 
-__global__ __launch_bounds__(256) void line_pairs_kernel(LineArgs a) {
-    const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    int* cnt = a.counters + b * 8;
-    const int n = cnt[3];
-    if (i >= n || j >= n || j <= i) return;
-    const uint8_t* out = a.kp_out + (size_t)b * a.max_num;
-    if (out[i] || out[j]) return;
-    const float* un = a.kp_un + (size_t)b * a.max_num * 2;
-    const float* heat = a.heat + (size_t)b * a.H * a.W;
+// three-point heat probe of PPGExtractor.cpp:304-313
+__device__ inline bool line_probe(const LineArgs& a, const float* un, const uint8_t* out, const float* heat, int i, int j) {
+    if (out[j]) return false;
     const float ix = un[2 * i], iy = un[2 * i + 1], jx = un[2 * j], jy = un[2 * j + 1];
     const float c1x = jx * 0.2f + ix * 0.8f, c1y = jy * 0.2f + iy * 0.8f;
-    if (heat_at(heat, a.W, (int)((double)c1y + 0.5), (int)((double)c1x + 0.5)) < a.heat_thresh) return;
+    if (heat_at(heat, a.W, (int)((double)c1y + 0.5), (int)((double)c1x + 0.5)) < a.heat_thresh) return false;
     const float c2x = jx * 0.8f + ix * 0.2f, c2y = jy * 0.8f + iy * 0.2f;
-    if (heat_at(heat, a.W, (int)((double)c2y + 0.5), (int)((double)c2x + 0.5)) < a.heat_thresh) return;
+    if (heat_at(heat, a.W, (int)((double)c2y + 0.5), (int)((double)c2x + 0.5)) < a.heat_thresh) return false;
     const float c3x = jx * 0.5f + ix * 0.5f, c3y = jy * 0.5f + iy * 0.5f;
-    if (heat_at(heat, a.W, (int)((double)c3y + 0.5), (int)((double)c3x + 0.5)) < a.heat_thresh) return;
-    const int k = atomicAdd(&cnt[2], 1);
-    if (k < a.cand_cap) a.cand_ij[(size_t)b * a.cand_cap + k] = ((uint32_t)i << 16) | (uint32_t)j;
+    if (heat_at(heat, a.W, (int)((double)c3y + 0.5), (int)((double)c3x + 0.5)) < a.heat_thresh) return false;
+    return true;
+}
+
+// Candidates leave the GPU already in the reference's loop order (i ascending, then j ascending):
+// pass 1 counts the survivors of every row i, a scan turns the counts into offsets, pass 2 repeats the
+// probe and writes each survivor at its ordered position (ballot prefix inside the work-group).
+template <bool EMIT>
+__global__ __launch_bounds__(256) void line_pairs_kernel(LineArgs a) {
+    __shared__ int wcnt[4];
+    const int b = blockIdx.y, i = blockIdx.x;
+    int* cnt = a.counters + b * 8;
+    const int n = cnt[3];
+    if (i >= n) return;
+    const uint8_t* out = a.kp_out + (size_t)b * a.max_num;
+    const float* un = a.kp_un + (size_t)b * a.max_num * 2;
+    const float* heat = a.heat + (size_t)b * a.H * a.W;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int* rowcnt = a.row_cnt + (size_t)b * (a.max_num + 1);
+    const bool row_ok = !out[i];
+    int base = EMIT ? rowcnt[i] : 0;  // after the scan rowcnt[i] holds the exclusive offset
+    for (int j0 = i + 1; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        const bool ok = row_ok && j < n && line_probe(a, un, out, heat, i, j);
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        if (EMIT) {
+            int off = base;
+            for (int w = 0; w < wave; w++) off += wcnt[w];
+            off += __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && off < a.cand_cap) a.cand_ij[(size_t)b * a.cand_cap + off] = ((uint32_t)i << 16) | (uint32_t)j;
+        }
+        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (!EMIT && tid == 0) rowcnt[i] = base;
+}
+
+// exclusive scan of the per-row counts of one frame (n <= 4096 rows), total -> counters[2]
+__global__ __launch_bounds__(1024) void line_scan_kernel(LineArgs a) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int* cnt = a.counters + b * 8;
+    const int n = cnt[3];
+    int* rowcnt = a.row_cnt + (size_t)b * (a.max_num + 1);
+    const int per = (n + 1023) / 1024;
+    int local = 0;
+    for (int k = 0; k < per; k++) {
+        const int r = tid * per + k;
+        if (r < n) local += rowcnt[r];
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - local;
+    for (int k = 0; k < per; k++) {
+        const int r = tid * per + k;
+        if (r < n) { const int c = rowcnt[r]; rowcnt[r] = run; run += c; }
+    }
+    if (tid == 1023) cnt[2] = part[1023];
 }
 
 __global__ __launch_bounds__(256) void line_score_kernel(LineArgs a) {
@@ -726,8 +783,10 @@ __global__ __launch_bounds__(256) void line_score_kernel(LineArgs a) {
 }
 
 hipError_t launch_line_candidates(const LineArgs& a, hipStream_t s) {
-    dim3 g1((a.max_num + 255) / 256, a.max_num, a.B);
-    hipLaunchKernelGGL(line_pairs_kernel, g1, dim3(256), 0, s, a);
+    dim3 g1(a.max_num, a.B);
+    hipLaunchKernelGGL(line_pairs_kernel<false>, g1, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(line_scan_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(line_pairs_kernel<true>, g1, dim3(256), 0, s, a);
     dim3 g2(64, a.B);
     hipLaunchKernelGGL(line_score_kernel, g2, dim3(256), 0, s, a);
     return hipGetLastError();
@@ -792,9 +851,12 @@ constexpr int DT = 64, DK = 16;
 
 __global__ __launch_bounds__(256) void dist_matrix_kernel(const float* __restrict__ A, int nA, const float* __restrict__ B,
                                                           int nB, int dim, float* __restrict__ D, int ldd,
-                                                          const int* nA_dev, const int* nB_dev) {
-    if (nA_dev) nA = *nA_dev;
-    if (nB_dev) nB = *nB_dev;
+                                                          const int* nA_dev, const int* nB_dev, size_t sA, size_t sB,
+                                                          size_t sD, int sn) {
+    const int bz = blockIdx.z;
+    A += bz * sA; B += bz * sB; D += bz * sD;
+    if (nA_dev) nA = min(nA, nA_dev[bz * sn]);
+    if (nB_dev) nB = min(nB, nB_dev[bz * sn]);
     const int r0 = blockIdx.y * DT, c0 = blockIdx.x * DT;
     if (r0 >= nA || c0 >= nB) return;
     __shared__ float As[DK][DT + 4];
@@ -844,14 +906,15 @@ hipError_t launch_dist_matrix(const float* A, int nA, const float* B, int nB, in
     if (nA <= 0 || nB <= 0) return hipSuccess;
     dim3 grid((nB + DT - 1) / DT, (nA + DT - 1) / DT);
     hipLaunchKernelGGL(dist_matrix_kernel, grid, dim3(256), 0, s, A, nA, B, nB, dim, D, ldd, (const int*)nullptr,
-                       (const int*)nullptr);
+                       (const int*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0);
     return hipGetLastError();
 }
 
-hipError_t launch_dist_matrix_dev(const float* A, const int* nA_dev, int maxA, const float* B, const int* nB_dev, int maxB,
-                                  int dim, float* D, int ldd, hipStream_t s) {
-    dim3 grid((maxB + DT - 1) / DT, (maxA + DT - 1) / DT);
-    hipLaunchKernelGGL(dist_matrix_kernel, grid, dim3(256), 0, s, A, maxA, B, maxB, dim, D, ldd, nA_dev, nB_dev);
+hipError_t launch_dist_matrix_batched(const float* A, const int* nA_dev, int maxA, size_t sA, const float* B,
+                                      const int* nB_dev, int maxB, size_t sB, int dim, float* D, int ldd, size_t sD,
+                                      int sn, int batch, hipStream_t s) {
+    dim3 grid((maxB + DT - 1) / DT, (maxA + DT - 1) / DT, batch);
+    hipLaunchKernelGGL(dist_matrix_kernel, grid, dim3(256), 0, s, A, maxA, B, maxB, dim, D, ldd, nA_dev, nB_dev, sA, sB, sD, sn);
     return hipGetLastError();
 }
 
@@ -918,6 +981,15 @@ __device__ inline Best2 best2_wave(Best2 v) {
     return v;
 }
 
+__device__ inline void apply_batch(MatchArgs& a, int b) {
+    a.D += b * a.bs_D;
+    a.topk_idx += b * a.bs_rows * 8; a.topk_dist += b * a.bs_rows * 8;
+    a.match12 += b * a.bs_rows; a.best += b * a.bs_rows; a.second += b * a.bs_rows;
+    if (a.nA_dev) a.nA_dev += b * a.bs_n;
+    if (a.nB_dev) a.nB_dev += b * a.bs_n;
+    a.n_matches += b;
+}
+
 __device__ inline void row_candidates(const MatchArgs& a, int row, int nB, const float** drow, const int32_t** irow, int* cnt) {
     if (a.ldd > 0) { *drow = a.D + (size_t)row * a.ldd; *irow = nullptr; *cnt = nB; }
     else { const int o0 = a.cand_off[row]; *drow = a.D + o0; *irow = a.cand_idx + o0; *cnt = a.cand_off[row + 1] - o0; }
@@ -925,7 +997,8 @@ __device__ inline void row_candidates(const MatchArgs& a, int row, int nB, const
 
 // PLAIN: one wave per A row
 __global__ __launch_bounds__(256) void match_plain_kernel(MatchArgs a) {
-    const int nA = a.nA_dev ? *a.nA_dev : a.nA, nB = a.nB_dev ? *a.nB_dev : a.nB;
+    apply_batch(a, blockIdx.y);
+    const int nA = a.nA_dev ? min(a.nA, *a.nA_dev) : a.nA, nB = a.nB_dev ? min(a.nB, *a.nB_dev) : a.nB;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nA) return;
     const float* drow; const int32_t* irow; int cnt;
@@ -944,7 +1017,7 @@ __global__ __launch_bounds__(256) void match_plain_kernel(MatchArgs a) {
 
 hipError_t launch_match_plain(const MatchArgs& a, hipStream_t s) {
     if (a.nA <= 0) return hipSuccess;
-    hipLaunchKernelGGL(match_plain_kernel, dim3((a.nA + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(match_plain_kernel, dim3((a.nA + 3) / 4, a.batch), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -954,7 +1027,8 @@ hipError_t launch_match_plain(const MatchArgs& a, hipStream_t s) {
 constexpr int TOPK = 8;
 
 __global__ __launch_bounds__(256) void match_topk_kernel(MatchArgs a) {
-    const int nA = a.nA_dev ? *a.nA_dev : a.nA, nB = a.nB_dev ? *a.nB_dev : a.nB;
+    apply_batch(a, blockIdx.y);
+    const int nA = a.nA_dev ? min(a.nA, *a.nA_dev) : a.nA, nB = a.nB_dev ? min(a.nB, *a.nB_dev) : a.nB;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nA) return;
     const float* drow; const int32_t* irow; int cnt;
@@ -1010,7 +1084,8 @@ constexpr int CLAIM_WORDS = 2048;  // up to 65536 B rows
 
 __global__ __launch_bounds__(64) void match_init_resolve_kernel(MatchArgs a) {
     __shared__ uint32_t claimed[CLAIM_WORDS];
-    const int nA = a.nA_dev ? *a.nA_dev : a.nA, nB = a.nB_dev ? *a.nB_dev : a.nB;
+    apply_batch(a, blockIdx.x);
+    const int nA = a.nA_dev ? min(a.nA, *a.nA_dev) : a.nA, nB = a.nB_dev ? min(a.nB, *a.nB_dev) : a.nB;
     const int lane = threadIdx.x;
     for (int k = lane; k < CLAIM_WORDS; k += 64) claimed[k] = 0;
     __syncthreads();
@@ -1077,8 +1152,8 @@ __global__ __launch_bounds__(64) void match_init_resolve_kernel(MatchArgs a) {
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
     const int rows = a.nA;
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(match_topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(match_init_resolve_kernel, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(match_topk_kernel, dim3((rows + 3) / 4, a.batch), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(match_init_resolve_kernel, dim3(a.batch), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

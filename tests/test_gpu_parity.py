@@ -280,6 +280,57 @@ def test_match_frames_resident(pkg, orc, synth):
     assert cnt > 400
 
 
+def test_match_prev_batch_resident(pkg, orc, synth):
+    """Two consecutive extract calls of 3 streams; every stream's frame t is matched against t+1 on the GPU."""
+    H, W = 96, 128
+    ctx = get_ctx(pkg, W, H, 500, batch=4)
+    cfg = orc.default_cfg(W, H)
+    scenes = [(1, "sparse"), (7, "dense"), (3, "sparse")]
+    r0 = ctx.extract_batch([synth.make_frame(H, W, s, 0, k) for s, k in scenes])
+    r1 = ctx.extract_batch([synth.make_frame(H, W, s, 1, k) for s, k in scenes])
+    cnts, m12 = ctx.match_prev_batch(3, 0.9)
+    for b in range(3):
+        co, mo, _ = orc.search_for_initialization(cfg, 0.9, r0[b]["desc"], r1[b]["desc"], r1[b]["un"], r0[b]["un"], 0)
+        assert cnts[b] == co and np.array_equal(m12[b, :r0[b]["n"]], mo) and np.all(m12[b, r0[b]["n"]:] == -1)
+    assert cnts.sum() > 20
+    with pytest.raises(pkg.PPGError):
+        ctx.match_prev_batch(4, 0.9)
+
+
+def test_pipelined_submit_wait_equals_blocking(pkg, synth):
+    """Two batches in flight: results (frames and matches) must equal the blocking calls bit for bit."""
+    H, W = 96, 128
+    ctx = get_ctx(pkg, W, H, 500, batch=4)
+    seqs = [[synth.make_frame(H, W, s, t, k) for s, k in ((1, "sparse"), (7, "dense"), (3, "sparse"))] for t in range(4)]
+    ref_frames, ref_matches = [], []
+    for t in range(4):
+        ref_frames.append(ctx.extract_batch(seqs[t]))
+        if t:
+            ref_matches.append(ctx.match_prev_batch(3, 0.9))
+    got = []
+    ctx.submit_batch(seqs[0], match_prev=False)
+    for t in range(1, 4):
+        ctx.submit_batch(seqs[t], match_prev=True)
+        with pytest.raises(pkg.PPGError, match="in flight"):
+            ctx.submit_batch(seqs[t])
+        with pytest.raises(pkg.PPGError, match="pending"):
+            ctx.extract(seqs[t][0])
+        got.append(ctx.wait_batch())
+    got.append(ctx.wait_batch())
+    with pytest.raises(pkg.PPGError, match="nothing was submitted"):
+        ctx.wait_batch()
+    for t in range(4):
+        frames, cnts, m12, n = got[t]
+        assert n == 3
+        for r, s in zip(frames, ref_frames[t]):
+            for k in ("xy", "score", "desc", "edge_idx", "conn_idx", "coline_pairs"):
+                assert np.array_equal(r[k], s[k], equal_nan=True), (t, k)
+        if t:
+            assert np.array_equal(cnts, ref_matches[t - 1][0]) and np.array_equal(m12, ref_matches[t - 1][1])
+        else:
+            assert not cnts.any() and np.all(m12 == -1)
+
+
 def test_grid_matches_oracle(pkg, orc):
     rng = np.random.default_rng(4)
     ctx = get_ctx(pkg, 640, 480)
