@@ -137,12 +137,17 @@ def main():
         stats["matches"] += int(cnts.sum())
 
     def run(first, count):
-        """`count` steps, software-pipelined two deep: the GPU works on batch k+1 while the host finishes k."""
-        submit(first)
-        for k in range(first + 1, first + count):
+        """`count` steps, software-pipelined three deep: CNN of batch k+2, post-processing of k+1 and the host's
+        line-graph tail of k overlap."""
+        depth, done = 3, first
+        for k in range(first, first + count):
             submit(k)
-            wait(k - 1)
-        wait(first + count - 1)
+            if k - done + 1 >= depth:
+                wait(done)
+                done += 1
+        while done < first + count:
+            wait(done)
+            done += 1
 
     run(0, args.warmup + 1)  # +1: the very first batch has no previous frame to match
     for key in stats:

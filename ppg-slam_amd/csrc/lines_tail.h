@@ -1,0 +1,185 @@
+// Host-side, order-dependent tail of detectLines.  Pure C++ (no HIP): included by ppg_front.cpp and by
+// the host micro-benchmark tools/bench_tail.cpp.  Must be compiled with -ffp-contract=off.
+#pragma once
+#include "../../include/ppgfront.h"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace {
+
+struct FrameHost {
+    std::vector<uint32_t> edge_idx;
+    std::vector<float> edge_score;
+    std::vector<int32_t> conn_off, coline_off;
+    std::vector<uint32_t> conn_idx, coline_pairs;
+};
+
+struct Cand {
+    uint32_t i, j;
+    float inlier, lscore_heat;
+    float dist;        // |Pj - Pi|                                   (:278-282)
+    float dir_ij;      // direction seen from i                        (:283)
+    float dir_ji;      // direction seen from j = dir_ij - pi, wrapped (:284-286)
+    float lscore;
+    float dir_from(uint32_t p) const { return p == i ? dir_ij : dir_ji; }
+    uint32_t other(uint32_t p) const { return p == i ? j : i; }
+};
+
+// One entry of a point's incidence list: what the overlap test needs about a line, stored inline so
+// that the walk over a list touches contiguous memory only.
+struct Inc {
+    float dir;     // direction of the line seen from this point
+    float dist;
+    uint32_t lid;  // index into TailScratch::lines
+};
+
+constexpr int kBuckets = 16;
+
+// Per-frame scratch that survives between calls so the tail allocates nothing in steady state.
+struct TailScratch {
+    std::vector<Cand> lines;
+    std::vector<uint8_t> bad;  // isBad per line
+    std::vector<std::vector<Inc>> conn;
+    std::vector<std::vector<uint32_t>> conn2;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Order-dependent tail of detectLines (feature/src/PPGExtractor.cpp:290-441) on the candidate list
+// the GPU produced.  Candidates arrive sorted by (i, j) — the reference's loop order — each with its
+// inlier rate and mean heat.  Everything here is O(candidates x live degree).
+// ---------------------------------------------------------------------------------------------
+const double kPi = 3.1415926535897932384626433832795, k2Pi = 6.283185307179586476925286766559;
+
+void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* ij, const float* sc, int nc,
+                FrameHost& fh, TailScratch& ts) {
+    std::vector<Cand>& lines = ts.lines;  // candidateLines of the reference (survivors of the overlap test)
+    std::vector<uint8_t>& bad = ts.bad;
+    lines.clear();
+    bad.clear();
+    if (ts.conn.size() < (size_t)n * kBuckets) { ts.conn.resize((size_t)n * kBuckets); ts.conn2.resize(n); }
+    std::vector<std::vector<Inc>>& conn = ts.conn;
+    for (size_t p = 0; p < (size_t)n * kBuckets; p++) conn[p].clear();
+    const float distTh = cfg.line_dist_thresh;
+    // Incidence lists are split into kBuckets direction sectors per point.  Only lines within 0.2*pi of
+    // the new direction can pass the angle gate of :326/:348, so the walk visits the sectors that can
+    // hold them (with slack for rounding) and skips the rest — the skipped entries would `continue`.
+    // The loop body has no early exit and its effects commute, so the visiting order is immaterial.
+    const float bscale = (float)(kBuckets / k2Pi);
+    auto sector = [&](float dir) -> int {
+        int b = (int)((dir + (float)kPi) * bscale);
+        return b < 0 ? 0 : (b >= kBuckets ? kBuckets - 1 : b);
+    };
+    auto overlap = [&](uint32_t a, float dirAB, float dNew) -> bool {  // :316-335 / :338-357
+        bool isOverlap = false;
+        const float slack = 0.2f * (float)kPi + 1e-3f;
+        const int b0 = (int)std::floor((dirAB - slack + (float)kPi) * bscale);
+        int b1 = (int)std::floor((dirAB + slack + (float)kPi) * bscale);
+        if (b1 - b0 >= kBuckets) b1 = b0 + kBuckets - 1;
+        for (int bb = b0; bb <= b1; bb++) {
+            std::vector<Inc>& lst = conn[(size_t)a * kBuckets + ((bb % kBuckets) + kBuckets) % kBuckets];
+            // Dead lines are skipped by the reference and never come back to life, so they are dropped
+            // from the list while walking it (keeps the walk proportional to the live degree).
+            size_t keep = 0;
+            const size_t len = lst.size();
+            for (size_t rd = 0; rd < len; rd++) {
+                const Inc e = lst[rd];
+                if (bad[e.lid]) continue;
+                lst[keep++] = e;
+                float ad = dirAB - e.dir;
+                if (ad < -kPi) ad = (float)(ad + k2Pi);
+                if (ad > kPi) ad = (float)(ad - k2Pi);
+                ad = std::fabs(ad);
+                if (ad > 0.2 * kPi) continue;
+                const float dOld = e.dist;
+                const float s = std::sin(ad);
+                if (dNew <= dOld && dNew * s < distTh) bad[e.lid] = 1;
+                if (dOld < dNew && dOld * s < distTh) isOverlap = true;
+            }
+            lst.resize(keep);
+        }
+        return isOverlap;
+    };
+    for (int k = 0; k < nc; k++) {
+        Cand cd;
+        cd.i = ij[k] >> 16; cd.j = ij[k] & 0xFFFFu;
+        float vx = un[2 * cd.j] - un[2 * cd.i], vy = un[2 * cd.j + 1] - un[2 * cd.i + 1];
+        cd.dist = std::sqrt(vx * vx + vy * vy);
+        vx = vx / cd.dist; vy = vy / cd.dist;
+        cd.dir_ij = std::atan2(vy, vx);
+        float r = (float)(cd.dir_ij - kPi);
+        if (r < -kPi) r = (float)(r + k2Pi);
+        cd.dir_ji = r;
+        if (overlap(cd.i, cd.dir_ij, cd.dist)) continue;
+        if (overlap(cd.j, cd.dir_ji, cd.dist)) continue;
+        cd.inlier = sc[2 * k]; cd.lscore_heat = sc[2 * k + 1];
+        cd.lscore = 0.f;
+        const uint32_t lid = (uint32_t)lines.size();
+        lines.push_back(cd);
+        bad.push_back(0);
+        conn[(size_t)cd.i * kBuckets + sector(cd.dir_ij)].push_back(Inc{cd.dir_ij, cd.dist, lid});
+        conn[(size_t)cd.j * kBuckets + sector(cd.dir_ji)].push_back(Inc{cd.dir_ji, cd.dist, lid});
+    }
+    std::vector<std::vector<uint32_t>>& c2 = ts.conn2;
+    for (int p = 0; p < n; p++) c2[p].clear();
+    for (uint32_t k = 0; k < lines.size(); k++) {  // :367-389
+        Cand& kl = lines[k];
+        if (bad[k]) continue;
+        if (kl.inlier < cfg.line_inlier_rate) { bad[k] = 1; continue; }
+        if (kl.lscore_heat < cfg.line_heatmap_thresh) { bad[k] = 1; continue; }
+        kl.lscore = kl.inlier * kl.lscore_heat;
+        c2[kl.i].push_back(k);
+        c2[kl.j].push_back(k);
+    }
+    fh.coline_off.assign(n + 1, 0);
+    fh.coline_pairs.clear();
+    std::vector<uint32_t> idx;
+    for (int p = 0; p < n; p++) {  // :392-432
+        fh.coline_off[p] = (int32_t)(fh.coline_pairs.size() / 2);
+        if (c2[p].size() < 2) continue;
+        idx = c2[p];
+        while (idx.size() > 1) {
+            double minDiff = 1e9;
+            int b1 = -1, b2 = -1, bestId = -1;
+            const Cand& kl1 = lines[idx.back()];
+            if (bad[idx.back()]) { idx.pop_back(); continue; }
+            for (uint32_t q = 0; q + 1 < idx.size(); q++) {
+                if (bad[idx[q]]) continue;
+                const Cand& kl2 = lines[idx[q]];
+                const float ad = kl1.dir_from(p) - kl2.dir_from(p);
+                const double pd = 0.5 * (kl1.dist + kl2.dist) * std::fabs(std::sin(ad));
+                if (minDiff > pd) { minDiff = pd; bestId = (int)q; b1 = (int)kl1.other(p); b2 = (int)kl2.other(p); }
+            }
+            if (minDiff > cfg.line_dist_thresh) { idx.pop_back(); continue; }
+            fh.coline_pairs.push_back((uint32_t)b1);
+            fh.coline_pairs.push_back((uint32_t)b2);
+            idx.pop_back();
+            idx[bestId] = idx.back();
+            idx.pop_back();
+        }
+    }
+    fh.coline_off[n] = (int32_t)(fh.coline_pairs.size() / 2);
+    fh.edge_idx.clear();
+    fh.edge_score.clear();
+    for (int p = 0; p < n; p++) c2[p].clear();
+    for (uint32_t k = 0; k < lines.size(); k++) {  // :433-441
+        if (bad[k]) continue;
+        const Cand& cl = lines[k];
+        const uint32_t e = (uint32_t)fh.edge_score.size();
+        fh.edge_idx.push_back(cl.i);
+        fh.edge_idx.push_back(cl.j);
+        fh.edge_score.push_back(cl.lscore);
+        c2[cl.i].push_back(e);
+        c2[cl.j].push_back(e);
+    }
+    fh.conn_off.assign(n + 1, 0);
+    fh.conn_idx.clear();
+    for (int p = 0; p < n; p++) {
+        fh.conn_off[p] = (int32_t)fh.conn_idx.size();
+        for (uint32_t e : c2[p]) fh.conn_idx.push_back(e);
+    }
+    fh.conn_off[n] = (int32_t)fh.conn_idx.size();
+}
+
+}  // namespace

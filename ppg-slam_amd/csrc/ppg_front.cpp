@@ -5,6 +5,7 @@
 // as the reference's -O3 build without FMA code generation does.
 #include "../../include/ppgfront.h"
 #include "ppg_kernels.h"
+#include "lines_tail.h"
 
 #include <algorithm>
 #include <chrono>
@@ -39,34 +40,13 @@ struct DBuf {
     size_t n = 0;
 };
 
-struct FrameHost {
-    std::vector<uint32_t> edge_idx;
-    std::vector<float> edge_score;
-    std::vector<int32_t> conn_off, coline_off;
-    std::vector<uint32_t> conn_idx, coline_pairs;
-};
-
-struct Cand {
-    uint32_t i, j;
-    float inlier, lscore_heat;
-    float dist;        // |Pj - Pi|                                   (:278-282)
-    float dir_ij;      // direction seen from i                        (:283)
-    float dir_ji;      // direction seen from j = dir_ij - pi, wrapped (:284-286)
-    bool bad;
-    float lscore;
-    float dir_from(uint32_t p) const { return p == i ? dir_ij : dir_ji; }
-    uint32_t other(uint32_t p) const { return p == i ? j : i; }
-};
-
-// Per-frame scratch that survives between calls so the tail allocates nothing in steady state.
-struct TailScratch {
-    std::vector<Cand> lines;
-    std::vector<std::vector<uint32_t>> conn;
-};
-
-// Everything a batch hands to the host lives twice, so that the GPU can work on batch k+1 while the host
-// finishes batch k (ppg_submit_batch_device / ppg_wait_batch).  The other slot also is "the previous
-// frame" of every stream for frame-to-frame matching.
+// Everything a batch hands to the host lives kSlots times (a ring), so that three batches can be in
+// flight: one in the CNN, one in post-processing / matching / copy-out, one in the host's line-graph tail
+// (ppg_submit_batch* / ppg_wait_batch).  The slot before the current one also is "the previous frame" of
+// every stream for frame-to-frame matching.
+constexpr int kSlots = 3;
+inline int next_slot(int s) { return (s + 1) % kSlots; }
+inline int prev_slot(int s) { return (s + kSlots - 1) % kSlots; }
 struct Slot {
     // device
     int* counters = nullptr;      // [B][8]: 0 resid, 1 kept, 2 line candidates, 3 key points
@@ -76,6 +56,8 @@ struct Slot {
     uint32_t* cand_ij = nullptr;
     int32_t* d_match = nullptr;   // [B][maxn]
     int* d_mcounts = nullptr;     // [B]
+    float *junc = nullptr, *hs2 = nullptr, *descmap = nullptr;  // CNN outputs read by the post stream
+    hipEvent_t cnn_done = nullptr;
     // pinned host mirrors
     int* h_counters = nullptr;
     int32_t* h_kp_xy = nullptr;
@@ -100,7 +82,9 @@ struct ppg_ctx {
     std::string weights_path;
     std::string err;
     int W = 0, H = 0, w8 = 0, h8 = 0, B = 0, maxn = 0;
-    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream = nullptr;       // CNN: image upload and every convolution
+    hipStream_t post = nullptr;         // everything after the CNN, matching, copies to the host
+    hipStream_t copy_stream = nullptr;  // late copies of an already finished slot
     std::vector<void*> dev_allocs, host_allocs;
     // weights
     DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
@@ -129,11 +113,11 @@ struct ppg_ctx {
     uint8_t* h_kp_out = nullptr;
     uint32_t* h_cand_ij = nullptr;
     std::vector<FrameHost>* frames = nullptr;
-    Slot slot[2];
+    Slot slot[kSlots];
     int cur = 0;  // slot the alias pointers above refer to
     std::vector<TailScratch> tails;
     int host_threads = 1;
-    bool skip_score = false, skip_refine = false;
+    bool skip_score = false, skip_heat = false, skip_refine = false;
     int last_n = 0;
     // previous extract call's descriptors / counts stay resident for frame-to-frame matching
     float* desc_prev = nullptr;
@@ -197,14 +181,15 @@ struct ProfScope {
     ppg_ctx* c;
     int cls;
     hipEvent_t e0 = nullptr;
-    ProfScope(ppg_ctx* ctx, int k) : c(ctx), cls(k) {
-        if (c->prof && (e0 = prof_event(c))) (void)hipEventRecord(e0, c->stream);
+    hipStream_t st;
+    ProfScope(ppg_ctx* ctx, int k, hipStream_t s) : c(ctx), cls(k), st(s) {
+        if (c->prof && (e0 = prof_event(c))) (void)hipEventRecord(e0, st);
     }
     ~ProfScope() {
         if (!e0) return;
         hipEvent_t e1 = prof_event(c);
         if (!e1) { c->ev_free.push_back(e0); return; }
-        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventRecord(e1, st);
         c->ev_pairs.push_back({cls, {e0, e1}});
     }
 };
@@ -228,9 +213,15 @@ void prof_resolve(ppg_ctx* c) {
     c->ev_pairs.resize(keep);
 }
 
+bool any_inflight(const ppg_ctx* c) {
+    for (const Slot& sl : c->slot)
+        if (sl.inflight) return true;
+    return false;
+}
+
 void select_slot(ppg_ctx* c, int sidx) {
     Slot& a = c->slot[sidx];
-    Slot& o = c->slot[sidx ^ 1];
+    Slot& o = c->slot[prev_slot(sidx)];
     c->cur = sidx;
     c->counters = a.counters; c->kp_xy = a.kp_xy; c->kp_score = a.kp_score; c->kp_un = a.kp_un; c->kp_out = a.kp_out;
     c->desc = a.desc; c->cand_ij = a.cand_ij; c->cand_sc = a.cand_sc; c->d_match = a.d_match; c->d_mcounts = a.d_mcounts;
@@ -238,6 +229,7 @@ void select_slot(ppg_ctx* c, int sidx) {
     c->h_kp_out = a.h_kp_out; c->h_desc = a.h_desc; c->h_cand_ij = a.h_cand_ij; c->h_cand_sc = a.h_cand_sc;
     c->h_match = a.h_match; c->h_mcounts = a.h_mcounts; c->frames = &a.frames; c->h_img = a.h_img;
     c->desc_prev = o.desc; c->counters_prev = o.counters;
+    c->junc = a.junc; c->hs2 = a.hs2; c->descmap = a.descmap;
 }
 
 bool read_blob(const char* path, std::map<std::string, Tensor>& out, std::string& why) {
@@ -415,7 +407,7 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
     a.B = n; a.H = H; a.W = W; a.Cin = dc.cin; a.Cout = dc.cout;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.nblk = dc.nblk;
     a.mode = mode; a.relu = relu;
-    ProfScope ps(c, dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER);
+    ProfScope ps(c, dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER, c->stream);
     HIPCHK(c, ppg::launch_conv(a, dc.ks, dc.nt, c->stream));
     return PPG_OK;
 }
@@ -438,122 +430,6 @@ ppg::HeatArgs heat_args(ppg_ctx* c, int n) {
     a.B = n; a.H = c->H; a.W = c->W; a.refine_sz = c->cfg.heatmap_refine_sz;
     a.valid_thresh = c->cfg.line_valid_thresh; a.valid_ratio = c->cfg.line_valid_ratio;
     return a;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Order-dependent tail of detectLines (feature/src/PPGExtractor.cpp:290-441) on the candidate list
-// the GPU produced.  Candidates arrive sorted by (i, j) — the reference's loop order — each with its
-// inlier rate and mean heat.  Everything here is O(candidates x degree).
-// ---------------------------------------------------------------------------------------------
-const double kPi = 3.1415926535897932384626433832795, k2Pi = 6.283185307179586476925286766559;
-
-void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* ij, const float* sc, int nc,
-                FrameHost& fh, TailScratch& ts) {
-    std::vector<Cand>& lines = ts.lines;  // candidateLines of the reference (survivors of the overlap test)
-    lines.clear();
-    if (ts.conn.size() < (size_t)n) ts.conn.resize(n);
-    std::vector<std::vector<uint32_t>>& conn = ts.conn;
-    for (int p = 0; p < n; p++) conn[p].clear();
-    auto overlap = [&](uint32_t a, float dirAB, float dNew) -> bool {  // :316-335 / :338-357
-        bool isOverlap = false;
-        // Dead lines are skipped by the reference and never come back to life, so they are dropped
-        // from the incidence list while walking it (keeps the walk proportional to the live degree).
-        std::vector<uint32_t>& lst = conn[a];
-        size_t keep = 0;
-        for (size_t rd = 0; rd < lst.size(); rd++) {
-            const uint32_t lid = lst[rd];
-            Cand& old = lines[lid];
-            if (old.bad) continue;
-            lst[keep++] = lid;
-            float ad = dirAB - old.dir_from(a);
-            if (ad < -kPi) ad = (float)(ad + k2Pi);
-            if (ad > kPi) ad = (float)(ad - k2Pi);
-            ad = std::fabs(ad);
-            if (ad > 0.2 * kPi) continue;
-            const float dOld = old.dist;
-            const float s = std::sin(ad);
-            if (dNew <= dOld && dNew * s < cfg.line_dist_thresh) old.bad = true;
-            if (dOld < dNew && dOld * s < cfg.line_dist_thresh) isOverlap = true;
-        }
-        lst.resize(keep);
-        return isOverlap;
-    };
-    for (int k = 0; k < nc; k++) {
-        Cand cd;
-        cd.i = ij[k] >> 16; cd.j = ij[k] & 0xFFFFu;
-        float vx = un[2 * cd.j] - un[2 * cd.i], vy = un[2 * cd.j + 1] - un[2 * cd.i + 1];
-        cd.dist = std::sqrt(vx * vx + vy * vy);
-        vx = vx / cd.dist; vy = vy / cd.dist;
-        cd.dir_ij = std::atan2(vy, vx);
-        float r = (float)(cd.dir_ij - kPi);
-        if (r < -kPi) r = (float)(r + k2Pi);
-        cd.dir_ji = r;
-        if (overlap(cd.i, cd.dir_ij, cd.dist)) continue;
-        if (overlap(cd.j, cd.dir_ji, cd.dist)) continue;
-        cd.inlier = sc[2 * k]; cd.lscore_heat = sc[2 * k + 1];
-        cd.bad = false; cd.lscore = 0.f;
-        lines.push_back(cd);
-        const uint32_t lid = (uint32_t)lines.size() - 1;
-        conn[cd.i].push_back(lid);
-        conn[cd.j].push_back(lid);
-    }
-    for (int p = 0; p < n; p++) conn[p].clear();
-    for (uint32_t k = 0; k < lines.size(); k++) {  // :367-389
-        Cand& kl = lines[k];
-        if (kl.bad) continue;
-        if (kl.inlier < cfg.line_inlier_rate) { kl.bad = true; continue; }
-        if (kl.lscore_heat < cfg.line_heatmap_thresh) { kl.bad = true; continue; }
-        kl.lscore = kl.inlier * kl.lscore_heat;
-        conn[kl.i].push_back(k);
-        conn[kl.j].push_back(k);
-    }
-    fh.coline_off.assign(n + 1, 0);
-    fh.coline_pairs.clear();
-    std::vector<uint32_t> idx;
-    for (int p = 0; p < n; p++) {  // :392-432
-        fh.coline_off[p] = (int32_t)(fh.coline_pairs.size() / 2);
-        if (conn[p].size() < 2) continue;
-        idx = conn[p];
-        while (idx.size() > 1) {
-            double minDiff = 1e9;
-            int b1 = -1, b2 = -1, bestId = -1;
-            const Cand& kl1 = lines[idx.back()];
-            if (kl1.bad) { idx.pop_back(); continue; }
-            for (uint32_t q = 0; q + 1 < idx.size(); q++) {
-                const Cand& kl2 = lines[idx[q]];
-                if (kl2.bad) continue;
-                const float ad = kl1.dir_from(p) - kl2.dir_from(p);
-                const double pd = 0.5 * (kl1.dist + kl2.dist) * std::fabs(std::sin(ad));
-                if (minDiff > pd) { minDiff = pd; bestId = (int)q; b1 = (int)kl1.other(p); b2 = (int)kl2.other(p); }
-            }
-            if (minDiff > cfg.line_dist_thresh) { idx.pop_back(); continue; }
-            fh.coline_pairs.push_back((uint32_t)b1);
-            fh.coline_pairs.push_back((uint32_t)b2);
-            idx.pop_back();
-            idx[bestId] = idx.back();
-            idx.pop_back();
-        }
-    }
-    fh.coline_off[n] = (int32_t)(fh.coline_pairs.size() / 2);
-    fh.edge_idx.clear();
-    fh.edge_score.clear();
-    for (int p = 0; p < n; p++) conn[p].clear();
-    for (const Cand& cl : lines) {  // :433-441
-        if (cl.bad) continue;
-        const uint32_t e = (uint32_t)fh.edge_score.size();
-        fh.edge_idx.push_back(cl.i);
-        fh.edge_idx.push_back(cl.j);
-        fh.edge_score.push_back(cl.lscore);
-        conn[cl.i].push_back(e);
-        conn[cl.j].push_back(e);
-    }
-    fh.conn_off.assign(n + 1, 0);
-    fh.conn_idx.clear();
-    for (int p = 0; p < n; p++) {
-        fh.conn_off[p] = (int32_t)fh.conn_idx.size();
-        for (uint32_t e : conn[p]) fh.conn_idx.push_back(e);
-    }
-    fh.conn_off[n] = (int32_t)fh.conn_idx.size();
 }
 
 size_t tensor_elems(const ppg_ctx* c, int which) {
@@ -607,6 +483,7 @@ void ppg_destroy(ppg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->post) (void)hipStreamSynchronize(c->post);
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
@@ -614,9 +491,12 @@ void ppg_destroy(ppg_ctx* c) {
     for (void* p : ms)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_all) (void)hipEventDestroy(e);
-    for (Slot& sl : c->slot)
+    for (Slot& sl : c->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.cnn_done) (void)hipEventDestroy(sl.cnn_done);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->post) (void)hipStreamDestroy(c->post);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
@@ -646,6 +526,7 @@ static int create_impl(ppg_ctx* c) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, PPG_EHIP, "device %d is %s; this library is built for gfx950 only", f.device_id, prop.gcnArchName);
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->post, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     int rc = load_weights(c);
     if (rc) return rc;
@@ -662,12 +543,9 @@ static int create_impl(ppg_ctx* c) {
     DA(a4, B * hw * 128);
     DA(feat, B * hw * 128);
     DA(pa_o, B * hw * 256);
-    DA(junc, B * hw * 65);
     DA(da_o, B * hw * 256);
-    DA(descmap, B * hw * 256);
     DA(hs0, B * hw * 4 * 64);
     DA(hs1, B * hw * 16 * 16);
-    DA(hs2, B * HW * 4);
     DA(heat_raw, B * HW * 2);
     DA(prob, B * HW);
     DA(refined, B * HW);
@@ -696,6 +574,9 @@ static int create_impl(ppg_ctx* c) {
         DS(cand_sc, B * c->cand_cap * 2);
         DS(d_match, B * c->maxn);
         DS(d_mcounts, B);
+        DS(junc, B * hw * 65);
+        DS(hs2, B * HW * 4);
+        DS(descmap, B * hw * 256);
         HS(h_counters, B * 8);
         HS(h_kp_xy, B * c->maxn * 2);
         HS(h_kp_score, B * c->maxn);
@@ -711,6 +592,7 @@ static int create_impl(ppg_ctx* c) {
 #undef HS
         HIPCHK(c, hipMemset(sl.counters, 0, sizeof(int) * 8 * B));
         HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.cnn_done, hipEventDisableTiming));
         sl.frames.resize(B);
         sl.nkp.assign(B, 0);
     }
@@ -724,10 +606,11 @@ static int create_impl(ppg_ctx* c) {
         c->host_threads = std::max(1, std::min(t, 64));
     }
     // warm-up on an all-ones image, as the reference constructor does (PPGExtractor.cpp:100-106)
+    // (at the full batch size, so that every kernel has run once at its production shape)
     std::vector<uint8_t> warm(HW, 1);
-    const uint8_t* wp = warm.data();
-    ppg_frame_out tmp;
-    return ppg_extract_batch(c, &wp, 1, c->W, &tmp);
+    std::vector<const uint8_t*> wp(B, warm.data());
+    std::vector<ppg_frame_out> tmp(B);
+    return ppg_extract_batch(c, wp.data(), (int)B, c->W, tmp.data());
 }
 
 ppg_ctx* ppg_create(const ppg_config* cfg) {
@@ -754,6 +637,7 @@ int ppg_read_tensor(ppg_ctx* c, int which, int frame, float* dst, size_t n) {
     if (!e || !dst || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_read_tensor: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->post));
     HIPCHK(c, hipMemcpy(dst, tensor_ptr(c, which) + (size_t)frame * e, e * sizeof(float), hipMemcpyDeviceToHost));
     return PPG_OK;
 }
@@ -764,10 +648,12 @@ int ppg_write_tensor(ppg_ctx* c, int which, int frame, const float* src, size_t 
     if (!e || !src || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_write_tensor: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->post));
     HIPCHK(c, hipMemcpy(tensor_ptr(c, which) + (size_t)frame * e, src, e * sizeof(float), hipMemcpyHostToDevice));
     // an injected map replaces the one the next stage call would compute from the network outputs
     if (which == PPG_T_SCORE) c->skip_score = true;
-    if (which == PPG_T_HEAT_REFINED) c->skip_refine = true;
+    if (which == PPG_T_HEAT || which == PPG_T_HEAT_RAW) c->skip_heat = true;
+    if (which == PPG_T_HEAT_REFINED) { c->skip_heat = true; c->skip_refine = true; }
     return PPG_OK;
 }
 
@@ -777,10 +663,10 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const size_t HW = (size_t)c->H * c->W;
     const uint8_t* dimg = imgs;
-    c->skip_score = c->skip_refine = false;
+    c->skip_score = c->skip_heat = c->skip_refine = false;
     {
-        const int ns = c->cur ^ 1;
-        if (c->slot[ns].inflight) return fail(c, PPG_EINVAL, "two batches are in flight: call ppg_wait_batch first");
+        const int ns = next_slot(c->cur);
+        if (c->slot[ns].inflight) return fail(c, PPG_EINVAL, "three batches are in flight: call ppg_wait_batch first");
         select_slot(c, ns);
         c->slot[ns].n = n;
         c->slot[ns].matched = false;
@@ -796,7 +682,7 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     ppg::Conv1aArgs a1;
     a1.img = dimg; a1.w = c->c1a_w; a1.bias = c->c1a_b; a1.out = c->a1; a1.B = n; a1.H = H; a1.W = W;
     {
-        ProfScope ps(c, PPG_PROF_CONV1A);
+        ProfScope ps(c, PPG_PROF_CONV1A, c->stream);
         HIPCHK(c, ppg::launch_conv1a(a1, c->stream));
     }
     int rc;
@@ -816,15 +702,11 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     RC(run_conv(c, c->h0, c->feat, c->hs0, n, H / 8, W / 8, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h1, c->hs0, c->hs1, n, H / 4, W / 4, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h2, c->hs1, c->hs2, n, H / 2, W / 2, ppg::CONV_PS2, 1));
-    {
-        ProfScope ps(c, PPG_PROF_POST);
-        ppg::HeatArgs ha = heat_args(c, n);
-        HIPCHK(c, ppg::launch_heat_tail(ha, c->stream));
-    }
     // Descriptor (descriptor_decoder.py:14-15)
     RC(run_conv(c, c->da, c->feat, c->da_o, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
     RC(run_conv(c, c->db, c->da_o, c->descmap, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
 #undef RC
+    HIPCHK(c, hipEventRecord(c->slot[c->cur].cnn_done, c->stream));
     c->last_n = n;
     return PPG_OK;
 }
@@ -833,11 +715,12 @@ int ppg_detect_keypoints(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    ProfScope ps(c, PPG_PROF_POST);
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(int) * 8 * n, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
+    ProfScope ps(c, PPG_PROF_POST, c->post);
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(int) * 8 * n, c->post));
     ppg::NmsArgs a = nms_args(c, n);
-    if (!c->skip_score) HIPCHK(c, ppg::launch_score_map(a, c->stream));
-    HIPCHK(c, ppg::launch_nms(a, c->stream));
+    if (!c->skip_score) HIPCHK(c, ppg::launch_score_map(a, c->post));
+    HIPCHK(c, ppg::launch_nms(a, c->post));
     return PPG_OK;
 }
 
@@ -847,16 +730,19 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     if (c->cfg.D[0] != 0.0f)
         return fail(c, PPG_EINVAL, "heat-map remap for D[0] != 0 (PPGExtractor.cpp:261-262) is not built");
-    ProfScope ps(c, PPG_PROF_POST);
+    HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
+    ProfScope ps(c, PPG_PROF_POST, c->post);
     ppg::HeatArgs ha = heat_args(c, n);
-    if (!c->skip_refine) HIPCHK(c, ppg::launch_refine(ha, c->stream));
+    // last layer of EdgeHeatmap (1x1 conv 4->2, heatmap_decoder.py:22) fused with the 2-way softmax of :242
+    if (!c->skip_heat) HIPCHK(c, ppg::launch_heat_tail(ha, c->post));
+    if (!c->skip_refine) HIPCHK(c, ppg::launch_refine(ha, c->post));
     ppg::LineArgs la;
     la.heat = c->refined; la.kp_un = c->kp_un; la.kp_out = c->kp_out; la.counters = c->counters;
     la.row_cnt = c->row_cnt; la.cand_ij = c->cand_ij; la.cand_sc = c->cand_sc; la.cand_cap = c->cand_cap;
     la.B = n; la.H = c->H; la.W = c->W; la.max_num = c->maxn;
     la.heat_thresh = c->cfg.line_heatmap_thresh;
     la.inv_scale = 1.0f / std::sqrt((float)(c->H * c->H + c->W * c->W));  // PPGExtractor.cpp:74
-    HIPCHK(c, ppg::launch_line_candidates(la, c->stream));
+    HIPCHK(c, ppg::launch_line_candidates(la, c->post));
     return PPG_OK;
 }
 
@@ -864,11 +750,12 @@ int ppg_gen_descriptors(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    ProfScope ps(c, PPG_PROF_POST);
+    HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
+    ProfScope ps(c, PPG_PROF_POST, c->post);
     ppg::DescArgs a;
     a.descmap = c->descmap; a.kp_xy = c->kp_xy; a.counters = c->counters; a.desc = c->desc;
     a.B = n; a.H = c->H; a.W = c->W; a.max_num = c->maxn;
-    HIPCHK(c, ppg::launch_desc_sample(a, c->stream));
+    HIPCHK(c, ppg::launch_desc_sample(a, c->post));
     return PPG_OK;
 }
 
@@ -876,7 +763,7 @@ int ppg_gen_descriptors(ppg_ctx* c, int n) {
 static int enqueue_d2h(ppg_ctx* c, int si, int n) {
     Slot& sl = c->slot[si];
     const int M = c->maxn;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->post;
     HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.counters, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_xy, sl.kp_xy, sizeof(int32_t) * 2 * M * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_score, sl.kp_score, sizeof(float) * M * n, hipMemcpyDeviceToHost, s));
@@ -999,7 +886,7 @@ static int enqueue_extract(ppg_ctx* c, const uint8_t* imgs, int n, int on_device
 }
 
 static int extract_common(ppg_ctx* c, const uint8_t* imgs, int n, int on_device, ppg_frame_out* outs) {
-    if (c->slot[0].inflight || c->slot[1].inflight)
+    if (any_inflight(c))
         return fail(c, PPG_EINVAL, "a submitted batch is pending: call ppg_wait_batch first");
     int rc = enqueue_extract(c, imgs, n, on_device);
     if (!rc) rc = ppg_collect(c, n, outs);
@@ -1045,8 +932,11 @@ int ppg_wait_batch(ppg_ctx* c, ppg_frame_out* outs, int32_t* m12, int* n_matches
     if (!c) return PPG_EINVAL;
     if (!outs) return fail(c, PPG_EINVAL, "ppg_wait_batch: outs is NULL");
     // slots alternate, so the older pending batch is the one that is not current (if it is pending)
-    int si = c->cur ^ 1;
-    if (!c->slot[si].inflight) si = c->cur;
+    int si = c->cur;
+    for (int k = 1; k <= kSlots; k++) {
+        si = (c->cur + k) % kSlots;
+        if (c->slot[si].inflight) break;
+    }
     Slot& sl = c->slot[si];
     if (!sl.inflight) return fail(c, PPG_EINVAL, "ppg_wait_batch: nothing was submitted");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -1057,7 +947,7 @@ int ppg_wait_batch(ppg_ctx* c, ppg_frame_out* outs, int32_t* m12, int* n_matches
     if (rc) return rc;
     if (c->prof) { c->prof_ms[PPG_PROF_HOST_FINISH] += now_ms() - t0; c->prof_launches[PPG_PROF_HOST_FINISH] += 1; }
     if (sl.matched) {
-        const Slot& prev = c->slot[si ^ 1];
+        const Slot& prev = c->slot[prev_slot(si)];
         for (int b = 0; b < n; b++) {
             if (m12) {
                 memcpy(m12 + (size_t)b * M, sl.h_match + (size_t)b * M, sizeof(int32_t) * prev.nkp[b]);
@@ -1076,8 +966,8 @@ int ppg_wait_batch(ppg_ctx* c, ppg_frame_out* outs, int32_t* m12, int* n_matches
 static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, const uint8_t** staged) {
     if (!imgs || n < 1 || n > c->B || row_stride < c->W)
         return fail(c, PPG_EINVAL, "bad image batch (n = %d, max_batch = %d, row_stride = %d)", n, c->B, row_stride);
-    Slot& nx = c->slot[c->cur ^ 1];
-    if (nx.inflight) return fail(c, PPG_EINVAL, "two batches are in flight: call ppg_wait_batch first");
+    Slot& nx = c->slot[next_slot(c->cur)];
+    if (nx.inflight) return fail(c, PPG_EINVAL, "three batches are in flight: call ppg_wait_batch first");
     const size_t HW = (size_t)c->H * c->W;
     for (int b = 0; b < n; b++) {
         if (!imgs[b]) return fail(c, PPG_EINVAL, "image %d is NULL", b);
@@ -1090,7 +980,7 @@ static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int 
 int ppg_extract_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, ppg_frame_out* outs) {
     if (!c) return PPG_EINVAL;
     if (!outs) return fail(c, PPG_EINVAL, "ppg_extract_batch: outs is NULL");
-    if (c->slot[0].inflight || c->slot[1].inflight)
+    if (any_inflight(c))
         return fail(c, PPG_EINVAL, "a submitted batch is pending: call ppg_wait_batch first");
     const uint8_t* staged = nullptr;
     int rc = stage_host_images(c, imgs, n, row_stride, &staged);
@@ -1122,7 +1012,7 @@ int ppg_dist_matrix(ppg_ctx* c, const float* A, int nA, const float* B, int nB, 
     if (!rc) rc = grow(c, c->mB, (size_t)nB * dim);
     if (!rc) rc = grow(c, c->mD, (size_t)nA * nB);
     if (rc) return rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->post;
     HIPCHK(c, hipMemcpyAsync(c->mA.p, A, sizeof(float) * nA * dim, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->mB.p, B, sizeof(float) * nB * dim, hipMemcpyHostToDevice, s));
     HIPCHK(c, ppg::launch_dist_matrix(c->mA.p, nA, c->mB.p, nB, dim, c->mD.p, nB, s));
@@ -1141,7 +1031,7 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     if (n_matches) *n_matches = 0;
     if (nA == 0) return PPG_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    hipStream_t s = c->stream;
+    hipStream_t s = c->post;
     const bool csr = cand_off != nullptr;
     const size_t nd = csr ? (size_t)cand_off[nA] : (size_t)nA * nB;
     if (csr) {
@@ -1326,8 +1216,8 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
     if (!rc) rc = grow(c, c->mTopD, (size_t)M * 8 * batch + 64);
     if (!rc) rc = grow(c, c->mTopI, (size_t)M * 8 * batch + 64);
     if (rc) return rc;
-    hipStream_t s = c->stream;
-    ProfScope ps(c, PPG_PROF_MATCH);
+    hipStream_t s = c->post;
+    ProfScope ps(c, PPG_PROF_MATCH, c->post);
     HIPCHK(c, ppg::launch_dist_matrix_batched(dA, nA, M, (size_t)M * 256, dB, nB, M, (size_t)M * 256, 256, c->mD.p, M,
                                               (size_t)M * M, 8, batch, s));
     ppg::MatchArgs m;
@@ -1343,7 +1233,7 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
 int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, int* n_matches) {
     if (!c) return PPG_EINVAL;
     Slot& sl = c->slot[c->cur];
-    if (sl.inflight || c->slot[c->cur ^ 1].inflight) return fail(c, PPG_EINVAL, "a submitted batch is pending");
+    if (any_inflight(c)) return fail(c, PPG_EINVAL, "a submitted batch is pending");
     if (fa < 0 || fb < 0 || fa >= sl.n || fb >= sl.n || !m12)
         return fail(c, PPG_EINVAL, "ppg_match_frames: frames must be in the last extracted batch");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -1351,9 +1241,9 @@ int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, in
     int rc = match_resident(c, c->desc + (size_t)fa * M * 256, c->counters + fa * 8 + 3, c->desc + (size_t)fb * M * 256,
                             c->counters + fb * 8 + 3, 1, nnratio, sl.d_match, sl.d_mcounts);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M, hipMemcpyDeviceToHost, c->post));
+    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int), hipMemcpyDeviceToHost, c->post));
+    HIPCHK(c, hipStreamSynchronize(c->post));
     if (c->prof) prof_resolve(c);
     memcpy(m12, sl.h_match, sizeof(int32_t) * sl.nkp[fa]);
     if (n_matches) *n_matches = sl.h_mcounts[0];
@@ -1363,17 +1253,17 @@ int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, in
 int ppg_match_prev_batch(ppg_ctx* c, int n, float nnratio, int32_t* m12, int* n_matches) {
     if (!c) return PPG_EINVAL;
     Slot& sl = c->slot[c->cur];
-    const Slot& prev = c->slot[c->cur ^ 1];
-    if (sl.inflight || prev.inflight) return fail(c, PPG_EINVAL, "a submitted batch is pending");
+    const Slot& prev = c->slot[prev_slot(c->cur)];
+    if (any_inflight(c)) return fail(c, PPG_EINVAL, "a submitted batch is pending");
     if (n < 1 || n > sl.n || n > prev.n || !m12)
         return fail(c, PPG_EINVAL, "ppg_match_prev_batch: needs two consecutive extract calls of >= n frames");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int M = c->maxn;
     int rc = match_resident(c, c->desc_prev, c->counters_prev + 3, c->desc, c->counters + 3, n, nnratio, sl.d_match, sl.d_mcounts);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, c->post));
+    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, c->post));
+    HIPCHK(c, hipStreamSynchronize(c->post));
     if (c->prof) prof_resolve(c);
     for (int b = 0; b < n; b++) {
         memcpy(m12 + (size_t)b * M, sl.h_match + (size_t)b * M, sizeof(int32_t) * prev.nkp[b]);

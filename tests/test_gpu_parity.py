@@ -41,6 +41,7 @@ def test_cnn_tensors_vs_reference_nets(name, pkg):
     ctx = get_ctx(pkg, W, H)
     ctx.inference([g["img"]])
     ctx.detect_keypoints(1)
+    ctx.detect_lines(1)  # the last 1x1 conv of EdgeHeatmap + softmax run at the head of this stage
     for which, k, rel in ((pkg.T_FEAT, "feat", 4e-6), (pkg.T_JUNC, "junc", 4e-6), (pkg.T_HEAT_RAW, "heat", 1e-5),
                           (pkg.T_DESCMAP, "desc", 4e-6)):
         got = ctx.read_tensor(which)
@@ -298,7 +299,7 @@ def test_match_prev_batch_resident(pkg, orc, synth):
 
 
 def test_pipelined_submit_wait_equals_blocking(pkg, synth):
-    """Two batches in flight: results (frames and matches) must equal the blocking calls bit for bit."""
+    """Three batches in flight: results (frames and matches) must equal the blocking calls bit for bit."""
     H, W = 96, 128
     ctx = get_ctx(pkg, W, H, 500, batch=4)
     seqs = [[synth.make_frame(H, W, s, t, k) for s, k in ((1, "sparse"), (7, "dense"), (3, "sparse"))] for t in range(4)]
@@ -309,13 +310,15 @@ def test_pipelined_submit_wait_equals_blocking(pkg, synth):
             ref_matches.append(ctx.match_prev_batch(3, 0.9))
     got = []
     ctx.submit_batch(seqs[0], match_prev=False)
-    for t in range(1, 4):
-        ctx.submit_batch(seqs[t], match_prev=True)
+    ctx.submit_batch(seqs[1], match_prev=True)
+    for t in range(2, 4):
+        ctx.submit_batch(seqs[t], match_prev=True)  # three batches in flight
         with pytest.raises(pkg.PPGError, match="in flight"):
             ctx.submit_batch(seqs[t])
         with pytest.raises(pkg.PPGError, match="pending"):
             ctx.extract(seqs[t][0])
         got.append(ctx.wait_batch())
+    got.append(ctx.wait_batch())
     got.append(ctx.wait_batch())
     with pytest.raises(pkg.PPGError, match="nothing was submitted"):
         ctx.wait_batch()
