@@ -114,7 +114,7 @@ def main():
         for t in range(T):
             host[t, s] = synth.frame_from_scene(scene, H, W, t)
     frames = torch.from_numpy(host).cuda()
-    seq = torch.zeros(1, dtype=torch.int32, device="cuda")
+    shutter = importlib.import_module("ppg_slam_amd.streams").ShutterBarrier(dist, "cuda")
 
     def barrier():
         torch.cuda.synchronize()
@@ -129,9 +129,7 @@ def main():
 
     def wait(k):
         outs, cnts, _, n = ctx.wait_batch(to_dict=False, want_matches=True)
-        if dist is not None:  # global-shutter barrier: release frame group k on every GPU together
-            seq.fill_(k)
-            dist.all_reduce(seq, op=dist.ReduceOp.MIN)
+        shutter.release(k)  # global-shutter barrier: frame group k is released on every GPU together
         stats["kp"] += sum(outs[b].n for b in range(n))
         stats["edges"] += sum(outs[b].n_edges for b in range(n))
         stats["matches"] += int(cnts.sum())

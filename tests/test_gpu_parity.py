@@ -385,3 +385,33 @@ def test_extend_map_matches_vs_oracle(pkg, orc, synth):
         cg, tg, pg, eg = ctx.extend_map_matches(*args)
         assert cg == co and np.array_equal(tg, to) and np.array_equal(pg, po) and np.array_equal(eg, eo)
         assert co > 50 and (eo >= 0).sum() > 0
+
+
+def test_host_mirror_program(pkg, synth, tmp_path):
+    """The C++ mirror (PPGExtractor::run + Matcher::SearchForInitialization) gives what the C ABI gives."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "ppg-slam_amd", "host", "shim_demo")
+    assert os.path.exists(demo), "build it with make -C ppg-slam_amd/csrc demo"
+    H, W = 96, 128
+    imgs = [synth.make_frame(H, W, 1, t, "sparse") for t in (0, 1)]
+    paths = []
+    for k, im in enumerate(imgs):
+        p = tmp_path / f"img{k}.raw"
+        p.write_bytes(im.tobytes())
+        paths.append(str(p))
+    out = subprocess.run([demo, os.path.dirname(pkg.DEFAULT_WEIGHTS), paths[0], paths[1], str(W), str(H)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    n0, e0, n1, conn0, nm, chk = [int(v) for v in out.stdout.split()]
+    ctx = get_ctx(pkg, W, H)
+    r0, r1 = ctx.extract(imgs[0]), ctx.extract(imgs[1])
+    cnt, m12, _ = ctx.search_for_initialization(0.9, r0["desc"], r1["desc"], r1["un"], r0["un"], 50)
+    ref = 0
+    for v in m12:
+        ref = (ref * 31 + (int(v) + 2)) & 0xFFFFFFFFFFFFFFFF
+    if ref >= 1 << 63:
+        ref -= 1 << 64
+    assert (n0, e0, n1, conn0, nm) == (r0["n"], r0["n_edges"], r1["n"], len(r0["conn_idx"]), cnt)
+    assert chk == ref

@@ -1,0 +1,66 @@
+"""world_size-2 gloo test of the multi-GPU path: stream sharding and the global-shutter barrier."""
+import importlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_pkg
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    load_pkg()
+    streams = importlib.import_module("ppg_slam_amd.streams")
+    mine = streams.shard_streams(8, world, rank)
+    bar = streams.ShutterBarrier(dist, "cpu")
+    released = []
+    for k in range(5):
+        done = k if rank == 0 else max(0, k - 1)  # rank 1 lags one frame group behind
+        released.append(bar.release(done))
+    # every rank sees the same release sequence = the slowest rank's progress
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, released))
+    q.put((rank, gathered))
+    dist.destroy_process_group()
+
+
+def test_sharding_and_barrier_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, gathered in res:
+        (s0, r0), (s1, r1) = gathered
+        assert sorted(s0 + s1) == list(range(8)) and not set(s0) & set(s1)
+        assert s0 == [0, 2, 4, 6] and s1 == [1, 3, 5, 7]
+        assert r0 == r1 == [0, 0, 1, 2, 3]
+
+
+def test_shard_streams_covers_everything():
+    load_pkg()
+    streams = importlib.import_module("ppg_slam_amd.streams")
+    for world in (1, 2, 4, 8):
+        got = sorted(s for r in range(world) for s in streams.shard_streams(19, world, r))
+        assert got == list(range(19))
+    with pytest.raises(ValueError):
+        streams.shard_streams(4, 2, 2)
