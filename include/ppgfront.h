@@ -213,9 +213,9 @@ void* ppg_stream(ppg_ctx* ctx);
 /* Device-time accounting with HIP events recorded on that stream around every launch (no counterpart in
  * the reference, which has no timers).  ppg_profile(ctx, 1) resets and enables, (ctx, 0) disables;
  * ppg_profile_read returns accumulated milliseconds and the number of timed launches per class. */
-#define PPG_PROF_CONV3X3 0     /* conv_mfma_kernel<3,2,8>: every 3x3 convolution with >= 64 couts */
+#define PPG_PROF_CONV3X3 0     /* conv_mfma_kernel<3,2,8,false>: the 3x3 convolutions with >= 64 couts after conv1b */
 #define PPG_PROF_CONV_OTHER 1  /* the 1x1 convolutions and the 16-cout 3x3 one */
-#define PPG_PROF_CONV1A 2
+#define PPG_PROF_CONV1A 2      /* conv_mfma_kernel<3,2,8,true>: conv1a fused into conv1b (or conv1a_kernel alone) */
 #define PPG_PROF_POST 3        /* score map, NMS, heat map, refine, line candidates, descriptors */
 #define PPG_PROF_MATCH 4
 #define PPG_PROF_HOST_WAIT 5   /* host wall time blocked in hipStreamSynchronize inside ppg_collect */

@@ -89,6 +89,7 @@ struct ppg_ctx {
     // weights
     DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
     float *c1a_w = nullptr, *c1a_b = nullptr, *h3_w = nullptr, *h3_b = nullptr;
+    float* heads_w = nullptr;  // packed weights of convPa | convDa | EdgeHeatmap block 0, concatenated
     // activations
     uint8_t* d_img = nullptr;
     float *a1 = nullptr, *p1 = nullptr, *a2 = nullptr, *p2 = nullptr, *a3 = nullptr, *p3 = nullptr, *a4 = nullptr,
@@ -118,6 +119,7 @@ struct ppg_ctx {
     std::vector<TailScratch> tails;
     int host_threads = 1;
     bool skip_score = false, skip_heat = false, skip_refine = false;
+    bool unfused_conv1a = false;
     int last_n = 0;
     // previous extract call's descriptors / counts stay resident for frame-to-frame matching
     float* desc_prev = nullptr;
@@ -386,6 +388,18 @@ int load_weights(ppg_ctx* c) {
     mk("edge.conv_block_lst.1.0", 2, true, "edge.conv_block_lst.1.1", c->h1);
     mk("edge.conv_block_lst.2.0", 1, true, "edge.conv_block_lst.2.1", c->h2);
     if (rc) return rc;
+    {
+        const DevConv* hs[3] = {&c->pa, &c->da, &c->h0};
+        size_t tot = 0, off = 0;
+        for (const DevConv* d : hs) tot += (size_t)d->nblk * 32 * d->nt * d->cin * 9;
+        rc = dalloc(c, &c->heads_w, tot);
+        if (rc) return rc;
+        for (const DevConv* d : hs) {
+            const size_t nfl = (size_t)d->nblk * 32 * d->nt * d->cin * 9;
+            HIPCHK(c, hipMemcpy(c->heads_w + off, d->w, nfl * sizeof(float), hipMemcpyDeviceToDevice));
+            off += nfl;
+        }
+    }
     auto w1 = t.find("backbone.conv1a.weight"), b1 = t.find("backbone.conv1a.bias");
     auto w3 = t.find("edge.conv_block_lst.3.weight"), b3 = t.find("edge.conv_block_lst.3.bias");
     if (w1 == t.end() || b1 == t.end() || w3 == t.end() || b3 == t.end() || w1->second.v.size() != 576 ||
@@ -401,14 +415,50 @@ int load_weights(ppg_ctx* c) {
     return rc;
 }
 
-int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, int H, int W, int mode, int relu) {
+// tile shape with the least padded area; the 16 x 16 tile exists for 3x3 layers with 64-cout blocks and no pooling
+int pick_tile(const DevConv& dc, int H, int W, int mode) {
+    if (dc.ks != 3 || dc.nt != 2 || mode == ppg::CONV_POOL2) return 32;
+    const long a32 = (long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32), a16 = (long)((H + 15) / 16 * 16) * ((W + 15) / 16 * 16);
+    return a16 < a32 ? 16 : 32;
+}
+
+ppg::ConvGroup conv_group(const DevConv& dc, float* out, int mode, int relu, int nblk0) {
+    ppg::ConvGroup g;
+    g.out = out; g.bias = dc.bias; g.alpha = dc.alpha; g.beta = dc.beta;
+    g.nblk0 = nblk0; g.Cout = dc.cout; g.mode = mode; g.relu = relu;
+    return g;
+}
+
+int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, int H, int W, int mode, int relu,
+             const uint8_t* fused_img = nullptr) {
     ppg::ConvArgs a;
-    a.in = in; a.wpk = dc.w; a.bias = dc.bias; a.alpha = dc.alpha; a.beta = dc.beta; a.out = out;
-    a.B = n; a.H = H; a.W = W; a.Cin = dc.cin; a.Cout = dc.cout;
-    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.nblk = dc.nblk;
-    a.mode = mode; a.relu = relu;
-    ProfScope ps(c, dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER, c->stream);
+    if (fused_img) { a.img = fused_img; a.w1a = c->c1a_w; a.b1a = c->c1a_b; }
+    a.in = in; a.wpk = dc.w;
+    a.B = n; a.H = H; a.W = W; a.Cin = dc.cin;
+    a.mw = fused_img ? 32 : pick_tile(dc, H, W, mode);
+    a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw); a.nblk = dc.nblk;
+    a.ngroups = 1;
+    a.g[0] = conv_group(dc, out, mode, relu, 0);
+    ProfScope ps(c, fused_img ? PPG_PROF_CONV1A : (dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER), c->stream);
     HIPCHK(c, ppg::launch_conv(a, dc.ks, dc.nt, c->stream));
+    return PPG_OK;
+}
+
+// convPa, convDa and the first EdgeHeatmap conv all read featureMap (128 -> 256, 3x3): one launch with
+// 12 cout blocks instead of three with 4, so the small 1/8-resolution grid fills the chip better.
+int run_heads(ppg_ctx* c, int n, int H, int W) {
+    ppg::ConvArgs a;
+    a.in = c->feat; a.wpk = c->heads_w;
+    a.B = n; a.H = H; a.W = W; a.Cin = c->pa.cin;
+    a.mw = pick_tile(c->pa, H, W, ppg::CONV_PLAIN);
+    a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
+    a.nblk = c->pa.nblk + c->da.nblk + c->h0.nblk;
+    a.ngroups = 3;
+    a.g[0] = conv_group(c->pa, c->pa_o, ppg::CONV_PLAIN, 1, 0);
+    a.g[1] = conv_group(c->da, c->da_o, ppg::CONV_PLAIN, 1, c->pa.nblk);
+    a.g[2] = conv_group(c->h0, c->hs0, ppg::CONV_PS2, 1, c->pa.nblk + c->da.nblk);
+    ProfScope ps(c, PPG_PROF_CONV3X3, c->stream);
+    HIPCHK(c, ppg::launch_conv(a, 3, 2, c->stream));
     return PPG_OK;
 }
 
@@ -601,6 +651,8 @@ static int create_impl(ppg_ctx* c) {
     select_slot(c, 0);
     c->tails.resize(B);
     {
+        const char* u = getenv("PPG_UNFUSED_CONV1A");
+        c->unfused_conv1a = u && atoi(u) != 0;
         const char* e = getenv("PPG_HOST_THREADS");
         int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         c->host_threads = std::max(1, std::min(t, 64));
@@ -679,16 +731,19 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
         dimg = c->d_img;
     }
     const int H = c->H, W = c->W;
-    ppg::Conv1aArgs a1;
-    a1.img = dimg; a1.w = c->c1a_w; a1.bias = c->c1a_b; a1.out = c->a1; a1.B = n; a1.H = H; a1.W = W;
-    {
+    // conv1a (u8 -> /255 -> conv 1->64 -> ReLU, backbone.py:28) is evaluated inside conv1b's staging, so the
+    // full-resolution 64-channel tensor never goes to memory; PPG_UNFUSED_CONV1A=1 keeps the separate kernel.
+    const bool fuse1a = !c->unfused_conv1a;
+    if (!fuse1a) {
+        ppg::Conv1aArgs a1;
+        a1.img = dimg; a1.w = c->c1a_w; a1.bias = c->c1a_b; a1.out = c->a1; a1.B = n; a1.H = H; a1.W = W;
         ProfScope ps(c, PPG_PROF_CONV1A, c->stream);
         HIPCHK(c, ppg::launch_conv1a(a1, c->stream));
     }
     int rc;
 #define RC(x) do { rc = (x); if (rc) return rc; } while (0)
     // Backbone (net/Backbone.pt backbone.py:28-37)
-    RC(run_conv(c, c->c1b, c->a1, c->p1, n, H, W, ppg::CONV_POOL2, 1));
+    RC(run_conv(c, c->c1b, c->a1, c->p1, n, H, W, ppg::CONV_POOL2, 1, fuse1a ? dimg : nullptr));
     RC(run_conv(c, c->c2a, c->p1, c->a2, n, H / 2, W / 2, ppg::CONV_PLAIN, 1));
     RC(run_conv(c, c->c2b, c->a2, c->p2, n, H / 2, W / 2, ppg::CONV_POOL2, 1));
     RC(run_conv(c, c->c3a, c->p2, c->a3, n, H / 4, W / 4, ppg::CONV_PLAIN, 1));
@@ -696,14 +751,12 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     RC(run_conv(c, c->c4a, c->p3, c->a4, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
     RC(run_conv(c, c->c4b, c->a4, c->feat, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
     // PointHeatmap (junction_decoder.py:14-15)
-    RC(run_conv(c, c->pa, c->feat, c->pa_o, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_heads(c, n, H / 8, W / 8));  // convPa + convDa + EdgeHeatmap block 0
     RC(run_conv(c, c->pb, c->pa_o, c->junc, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
     // EdgeHeatmap (heatmap_decoder.py:19-22); the last 1x1 conv runs in ppg_detect_lines' first kernel
-    RC(run_conv(c, c->h0, c->feat, c->hs0, n, H / 8, W / 8, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h1, c->hs0, c->hs1, n, H / 4, W / 4, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h2, c->hs1, c->hs2, n, H / 2, W / 2, ppg::CONV_PS2, 1));
     // Descriptor (descriptor_decoder.py:14-15)
-    RC(run_conv(c, c->da, c->feat, c->da_o, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
     RC(run_conv(c, c->db, c->da_o, c->descmap, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
 #undef RC
     HIPCHK(c, hipEventRecord(c->slot[c->cur].cnn_done, c->stream));

@@ -8,17 +8,30 @@ namespace ppg {
 // ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ----
 enum ConvMode { CONV_PLAIN = 0, CONV_POOL2 = 1, CONV_PS2 = 2 };
 
+// One layer served by a launch: its cout blocks start at nblk0; bias/alpha/beta are indexed by the
+// layer's own packed cout.
+struct ConvGroup {
+    float* out = nullptr;
+    const float* bias = nullptr;
+    const float* alpha = nullptr;  // eval-mode batch-norm scale or nullptr
+    const float* beta = nullptr;   // eval-mode batch-norm shift
+    int nblk0 = 0;
+    int Cout = 0;
+    int mode = 0;                  // ConvMode
+    int relu = 0;
+};
+
 struct ConvArgs {
-    const float* in;     // [B][H][W][Cin] channels-last
-    const float* wpk;    // packed per (cout block, cin chunk): see pack_conv_weights()
-    const float* bias;   // [nblk*NB] (zero padded)
-    const float* alpha;  // eval-mode batch-norm scale or nullptr
-    const float* beta;   // eval-mode batch-norm shift
-    float* out;
-    int B, H, W, Cin, Cout;
-    int tiles_x, tiles_y, nblk;
-    int mode;            // ConvMode
-    int relu;
+    const float* in;     // [B][H][W][Cin] channels-last (unused when img != nullptr)
+    const uint8_t* img = nullptr;  // fused first layer: [B][H][W] image; this conv's input is conv1a(img)
+    const float* w1a = nullptr;    // [9][64] conv1a weights, tap-major
+    const float* b1a = nullptr;    // [64]
+    const float* wpk;    // packed per (cout block, cin chunk), the blocks of all groups concatenated
+    int B, H, W, Cin;
+    int tiles_x, tiles_y, nblk;  // nblk = cout blocks of all groups together
+    int mw = 32;         // tile shape: 32 -> 8 x 32 pixels, 16 -> 16 x 16 pixels (3x3, 64-cout blocks only)
+    int ngroups = 1;
+    ConvGroup g[3];
 };
 
 // ks: 1 or 3; nt: 32-wide cout tiles per wave (1 or 2)

@@ -33,10 +33,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // exactly the LDS image order.  Two LDS buffers: the next chunk is fetched into registers before the
 // MFMAs of the current one and written to the other buffer after them, one barrier per chunk.
 // =====================================================================================
-constexpr int TH = 8, TW = 32;
-
-template <int KS, int NT, int KC>
+// Two tile shapes (MW = width of one 32-pixel M tile): MW = 32 -> 8 rows x 32 columns per work-group (an M
+// tile is one row segment), MW = 16 -> 16 x 16 (an M tile is 2 rows x 16 columns), which wastes less of
+// feature maps whose width is a multiple of 16 but not of 32 (e.g. 80 columns at 640/8).
+template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int TW = MW, TH = 256 / MW;
     constexpr int PAD = KS / 2;
     constexpr int IH = TH + KS - 1, IW = TW + KS - 1, IN_PIX = IH * IW;
     constexpr int PSTR = KC + 4;
@@ -50,7 +52,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     constexpr int W_ITEMS = W_FLOATS / 4;
     constexpr int W_PER_T = (W_ITEMS + 255) / 256;
     constexpr int BUF = IN_FLOATS + W_FLOATS;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+    // FUSE1A: the input of this layer is conv1a(image) and is computed on the fly from the u8 patch of
+    // the tile (two halo rings) instead of being read from memory: patch as floats + conv1a weights.
+    constexpr int PH = IH + 2, PW = IW + 2;
+    constexpr int FUSE_FLOATS = FUSE1A ? (PH * PW + 9 * 64 + 64) : 0;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF + FUSE_FLOATS];
+    float* patch = smem + 2 * BUF;           // [PH][PW]
+    float* w1s = patch + PH * PW;            // [9][64]
+    float* b1s = w1s + 9 * 64;               // [64]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int bx = blockIdx.x;
@@ -58,8 +67,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     const int nb = blockIdx.y;
     const int x0 = tx * TW, y0 = ty * TH;
     const int nchunks = a.Cin / KC;
+    // pixel (row, column) inside the tile of A-operand lane li / accumulator row index i of M tile m
+    auto prow = [&](int m, int i) { return MW == 32 ? 2 * wave + m : 4 * wave + 2 * m + (i >> 4); };
+    auto pcol = [&](int i) { return MW == 32 ? i : (i & 15); };
 
-    long gofs[IN_PER_T];
+    long gofs[IN_PER_T];  // FUSE1A: >= 0 means "inside the image"; the value is the patch offset of the pixel
     int lofs[IN_PER_T];
 #pragma unroll
     for (int k = 0; k < IN_PER_T; k++) {
@@ -72,8 +84,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
             const int gy = y0 + py - PAD, gx = x0 + px - PAD;
             lofs[k] = pix * PSTR + q * 4;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                gofs[k] = ((long)(b * a.H + gy) * a.W + gx) * a.Cin + q * 4;
+                gofs[k] = FUSE1A ? (long)(py * PW + px) : ((long)(b * a.H + gy) * a.W + gx) * a.Cin + q * 4;
         }
+    }
+    if (FUSE1A) {
+        // patch pixel (py, px) = image pixel (y0 - 2 + py, x0 - 2 + px); u8 -> f32 by a true division
+        // (feature/src/PPGExtractor.cpp:151), zero outside the image (conv1a's own zero padding)
+        const uint8_t* im = a.img + (size_t)b * a.H * a.W;
+        for (int i = tid; i < PH * PW; i += 256) {
+            const int gy = y0 - 2 + i / PW, gx = x0 - 2 + i % PW;
+            float v = 0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = (float)im[(size_t)gy * a.W + gx] / 255.0f;
+            patch[i] = v;
+        }
+        for (int i = tid; i < 9 * 64; i += 256) w1s[i] = a.w1a[i];
+        if (tid < 64) b1s[tid] = a.b1a[tid];
+        __syncthreads();
     }
     const float* wsrc = a.wpk + (size_t)nb * nchunks * W_FLOATS;
 
@@ -82,7 +108,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < IN_PER_T; k++) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            vin[k] = gofs[k] >= 0 ? *(const f32x4*)(a.in + gofs[k] + c * KC) : z;
+            if (!FUSE1A) {
+                vin[k] = gofs[k] >= 0 ? *(const f32x4*)(a.in + gofs[k] + c * KC) : z;
+            } else {
+                // conv1a + ReLU for 4 channels of one pixel: bias, then the nine taps in (ky, kx) order, fmaf
+                // (backbone.py:28) — the same chain as conv1a_kernel.  Pixels outside the image are this
+                // layer's zero padding.
+                vin[k] = z;
+                if (gofs[k] >= 0) {
+                    const int ch = c * KC + ((tid + 256 * k) % QPP) * 4;
+                    f32x4 acc = *(const f32x4*)(b1s + ch);
+                    const float* pp = patch + gofs[k];
+#pragma unroll
+                    for (int t = 0; t < 9; t++) {
+                        const float v = pp[(t / 3) * PW + (t % 3)];
+                        const f32x4 w = *(const f32x4*)(w1s + t * 64 + ch);
+                        acc[0] = fmaf(v, w[0], acc[0]); acc[1] = fmaf(v, w[1], acc[1]);
+                        acc[2] = fmaf(v, w[2], acc[2]); acc[3] = fmaf(v, w[3], acc[3]);
+                    }
+                    acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f);
+                    acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f);
+                    vin[k] = acc;
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < W_PER_T; k++) {
@@ -128,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
                 f32x4 av[2], bv[NT];
 #pragma unroll
                 for (int m = 0; m < 2; m++)
-                    av[m] = *(const f32x4*)(ins + ((2 * wave + m + ky) * IW + (li + kx)) * PSTR + g * 8 + lh * 4);
+                    av[m] = *(const f32x4*)(ins + ((prow(m, li) + ky) * IW + (pcol(li) + kx)) * PSTR + g * 8 + lh * 4);
 #pragma unroll
                 for (int n = 0; n < NT; n++)
                     bv[n] = *(const f32x4*)(ws + (((g * TAPS + tap) * 2 + lh) * NB + n * 32 + li) * 4);
@@ -146,16 +194,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store ----
-    const int yrow = y0 + 2 * wave;
+    // A launch may serve up to three layers that read the same input (cout blocks [nblk0, next nblk0) each)
+    int gi = 0;
+    if (a.ngroups > 1 && nb >= a.g[1].nblk0) gi = 1;
+    if (a.ngroups > 2 && nb >= a.g[2].nblk0) gi = 2;
+    const ConvGroup G = a.g[gi];
 #pragma unroll
     for (int n = 0; n < NT; n++) {
-        const int co = nb * NB + n * 32 + li;
-        const float bias = a.bias[co];
+        const int co = (nb - G.nblk0) * NB + n * 32 + li;  // cout inside this layer (packed order)
+        const float bias = G.bias[co];
         float al = 1.f, be = 0.f;
-        const bool bn = a.alpha != nullptr;
-        if (bn) { al = a.alpha[co]; be = a.beta[co]; }
-        if (co >= a.Cout) continue;
-        if (a.mode == CONV_POOL2) {
+        const bool bn = G.alpha != nullptr;
+        if (bn) { al = G.alpha[co]; be = G.beta[co]; }
+        if (co >= G.Cout) continue;
+        if (G.mode == CONV_POOL2) {
+            if (MW != 32) continue;  // pooled layers always use the 8 x 32 tile
+            const int yrow = y0 + 2 * wave;
             const int Hp = a.H / 2, Wp = a.W / 2;
             if (yrow + 1 < a.H) {
 #pragma unroll
@@ -165,30 +219,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
                     if (x + 1 < a.W) {
                         float v = fmaxf(fmaxf(acc[0][n][r0], acc[0][n][r0 + 1]), fmaxf(acc[1][n][r0], acc[1][n][r0 + 1]));
                         v = v + bias;
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        a.out[((size_t)(b * Hp + (yrow >> 1)) * Wp + (x >> 1)) * a.Cout + co] = v;
+                        if (G.relu) v = fmaxf(v, 0.f);
+                        G.out[((size_t)(b * Hp + (yrow >> 1)) * Wp + (x >> 1)) * G.Cout + co] = v;
                     }
                 }
             }
         } else {
 #pragma unroll
             for (int m = 0; m < 2; m++) {
-                const int y = yrow + m;
-                if (y >= a.H) continue;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (x >= a.W) continue;
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int y = y0 + prow(m, i), x = x0 + pcol(i);
+                    if (y >= a.H || x >= a.W) continue;
                     float v = acc[m][n][r] + bias;
                     if (bn) v = v * al + be;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.mode == CONV_PLAIN) {
-                        a.out[((size_t)(b * a.H + y) * a.W + x) * a.Cout + co] = v;
+                    if (G.relu) v = fmaxf(v, 0.f);
+                    if (G.mode == CONV_PLAIN) {
+                        G.out[((size_t)(b * a.H + y) * a.W + x) * G.Cout + co] = v;
                     } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx
-                        const int Cps = a.Cout >> 2;
+                        const int Cps = G.Cout >> 2;
                         const int q = co / Cps, cc = co - q * Cps;
                         const int Y = 2 * y + (q >> 1), X = 2 * x + (q & 1);
-                        a.out[((size_t)(b * 2 * a.H + Y) * (2 * a.W) + X) * Cps + cc] = v;
+                        G.out[((size_t)(b * 2 * a.H + Y) * (2 * a.W) + X) * Cps + cc] = v;
                     }
                 }
             }
@@ -200,7 +253,10 @@ int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
 
 hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
-    if (ks == 3 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8>), grid, block, 0, s, a);
+    if (a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
+    if (ks == 3 && nt == 2 && a.img) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true>), grid, block, 0, s, a);
+    else if (ks == 3 && nt == 2 && a.mw == 16) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16>), grid, block, 0, s, a);
+    else if (ks == 3 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8>), grid, block, 0, s, a);
     else if (ks == 1 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 16>), grid, block, 0, s, a);
     else if (ks == 1 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 16>), grid, block, 0, s, a);
@@ -314,19 +370,36 @@ __device__ inline bool beats(float sq, int dy, int dx, float sp) {
     return sq > sp || (sq == sp && (dy < 0 || (dy == 0 && dx < 0)));
 }
 
+// 64-bit priority of a candidate pixel: larger = better.  Scores are positive floats, so their bit
+// patterns order like the values; ties go to the smaller row-major index.  0 = not a candidate.
+__device__ inline unsigned long long prio_key(float s, uint32_t idx) {
+    return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// Pass A: a candidate is kept at once iff it is the best pixel of its own 9x9 window.  The window
+// maximum of a total order is separable: row maxima over 9 columns, then column maxima over 9 rows.
 __global__ __launch_bounds__(256) void nms_local_max_kernel(NmsArgs a) {
-    __shared__ float sh[NT_LD][NT_LD + 1];
+    __shared__ unsigned long long key[NT_LD][NT_LD + 1];
+    __shared__ unsigned long long rowmax[NT_LD][NT_TILE + 1];
     const int b = blockIdx.z, ox = blockIdx.x * NT_TILE, oy = blockIdx.y * NT_TILE;
     const float* sc = a.score + (size_t)b * a.H * a.W;
     for (int i = threadIdx.x; i < NT_LD * NT_LD; i += 256) {
         const int ly = i / NT_LD, lx = i % NT_LD;
         const int gy = oy + ly - NR, gx = ox + lx - NR;
-        float v = -1.f;
+        unsigned long long v = 0;
         if (gx >= NR && gx <= a.W - NR - 1 && gy >= NR && gy <= a.H - NR - 1) {
             const float s = sc[(size_t)gy * a.W + gx];
-            if (!(s < a.thresh)) v = s;
+            if (!(s < a.thresh)) v = prio_key(s, (uint32_t)(gy * a.W + gx));
         }
-        sh[ly][lx] = v;
+        key[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT_LD * NT_TILE; i += 256) {
+        const int ly = i / NT_TILE, lx = i % NT_TILE;
+        unsigned long long m = 0;
+#pragma unroll
+        for (int d = 0; d <= 2 * NR; d++) { const unsigned long long v = key[ly][lx + d]; m = v > m ? v : m; }
+        rowmax[ly][lx] = m;
     }
     __syncthreads();
     uint8_t* st = a.state + (size_t)b * a.H * a.W;
@@ -334,23 +407,20 @@ __global__ __launch_bounds__(256) void nms_local_max_kernel(NmsArgs a) {
         const int ly = i / NT_TILE, lx = i % NT_TILE;
         const int gy = oy + ly, gx = ox + lx;
         if (gy >= a.H || gx >= a.W) continue;
-        const float sp = sh[ly + NR][lx + NR];
-        uint8_t r = 0;
-        if (sp >= 0.f) {
-            bool beaten = false;
-            for (int dy = -NR; dy <= NR && !beaten; dy++)
-                for (int dx = -NR; dx <= NR; dx++) {
-                    const float sq = sh[ly + NR + dy][lx + NR + dx];
-                    if (sq >= 0.f && (dy | dx) != 0 && beats(sq, dy, dx, sp)) { beaten = true; break; }
-                }
-            r = beaten ? 1 : 2;
-        }
-        st[(size_t)gy * a.W + gx] = r;
+        unsigned long long m = 0;
+#pragma unroll
+        for (int d = 0; d <= 2 * NR; d++) { const unsigned long long v = rowmax[ly + d][lx]; m = v > m ? v : m; }
+        const unsigned long long me = key[ly + NR][lx + NR];
+        st[(size_t)gy * a.W + gx] = me == 0 ? 0 : (me == m ? 2 : 1);
     }
 }
 
+// Pass B: an undecided candidate with a kept pixel in its window is suppressed (that pixel beats it,
+// being the best of a window that contains this one); the rest go to the residual list.  "Any kept
+// pixel in the window" is separable in the same way.
 __global__ __launch_bounds__(256) void nms_suppress_kernel(NmsArgs a) {
     __shared__ uint8_t sh[NT_LD][NT_LD + 8];
+    __shared__ uint8_t rowany[NT_LD][NT_TILE + 8];
     const int b = blockIdx.z, ox = blockIdx.x * NT_TILE, oy = blockIdx.y * NT_TILE;
     uint8_t* st = a.state + (size_t)b * a.H * a.W;
     for (int i = threadIdx.x; i < NT_LD * NT_LD; i += 256) {
@@ -359,6 +429,14 @@ __global__ __launch_bounds__(256) void nms_suppress_kernel(NmsArgs a) {
         uint8_t v = 0;
         if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) v = st[(size_t)gy * a.W + gx];
         sh[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT_LD * NT_TILE; i += 256) {
+        const int ly = i / NT_TILE, lx = i % NT_TILE;
+        uint8_t any = 0;
+#pragma unroll
+        for (int d = 0; d <= 2 * NR; d++) any |= (uint8_t)(sh[ly][lx + d] == 2);
+        rowany[ly][lx] = any;
     }
     __syncthreads();
     int* cnt = a.counters + b * 8;
@@ -372,10 +450,9 @@ __global__ __launch_bounds__(256) void nms_suppress_kernel(NmsArgs a) {
             const int k = atomicAdd(&cnt[1], 1);
             if (k < a.kept_cap) a.kept[(size_t)b * a.kept_cap + k] = idx;
         } else if (s0 == 1) {
-            bool sup = false;
-            for (int dy = -NR; dy <= NR && !sup; dy++)
-                for (int dx = -NR; dx <= NR; dx++)
-                    if (sh[ly + NR + dy][lx + NR + dx] == 2) { sup = true; break; }
+            uint8_t sup = 0;
+#pragma unroll
+            for (int d = 0; d <= 2 * NR; d++) sup |= rowany[ly + d][lx];
             if (sup) {
                 // only this thread writes this pixel; neighbours test for == 2 only, which never changes here
                 st[idx] = 3;
@@ -471,40 +548,61 @@ __device__ inline void undistort_fisheye_dev(const NmsArgs& a, float x, float y,
     *ov = (float)(fy * (py * scale) + cy);
 }
 
+constexpr int EMIT_SORT_CAP = 8192;  // keys sorted in LDS (64 KiB); larger sets are ranked by counting
+
+__device__ inline void emit_point(const NmsArgs& a, int b, const float* sc, uint32_t p, int rank) {
+    const int x = (int)(p % (uint32_t)a.W), y = (int)(p / (uint32_t)a.W);
+    const size_t o = (size_t)b * a.max_num + rank;
+    a.kp_xy[2 * o] = x;
+    a.kp_xy[2 * o + 1] = y;
+    a.kp_score[o] = sc[p];
+    float u, v;
+    if (a.fisheye) undistort_fisheye_dev(a, (float)x, (float)y, &u, &v);
+    else undistort_pinhole_dev(a, (float)x, (float)y, &u, &v);
+    a.kp_un[2 * o] = u;
+    a.kp_un[2 * o + 1] = v;
+    a.kp_out[o] = !(u >= 1 && u < a.W - 1 && v >= 1 && v < a.H - 1);
+}
+
+// Pass D: order the kept pixels by priority and emit the best max_num (the reference's sorted visit
+// order with its early break at JUNCTION_MAX_NUM, PPGExtractor.cpp:180, :195-196).
 __global__ __launch_bounds__(1024) void nms_emit_kernel(NmsArgs a) {
-    const int b = blockIdx.x;
+    __shared__ unsigned long long skey[EMIT_SORT_CAP];
+    const int b = blockIdx.x, tid = threadIdx.x;
     int* cnt = a.counters + b * 8;
     const int S = min(cnt[1], a.kept_cap);
     const float* sc = a.score + (size_t)b * a.H * a.W;
     const uint32_t* kept = a.kept + (size_t)b * a.kept_cap;
-    unsigned long long* key = a.kept_key + (size_t)b * a.kept_cap;
-    // key: larger = better.  Scores are positive floats, so their bit patterns order like the values.
-    for (int k = threadIdx.x; k < S; k += 1024) {
-        const uint32_t p = kept[k];
-        key[k] = ((unsigned long long)__float_as_uint(sc[p]) << 32) | (unsigned long long)(0xFFFFFFFFu - p);
-    }
-    __syncthreads();
     const int n = min(S, a.max_num);
-    for (int k = threadIdx.x; k < S; k += 1024) {
-        const unsigned long long mine = key[k];
-        int rank = 0;
-        for (int j = 0; j < S; j++) rank += key[j] > mine;
-        if (rank < n) {
-            const uint32_t p = kept[k];
-            const int x = (int)(p % (uint32_t)a.W), y = (int)(p / (uint32_t)a.W);
-            const size_t o = (size_t)b * a.max_num + rank;
-            a.kp_xy[2 * o] = x;
-            a.kp_xy[2 * o + 1] = y;
-            a.kp_score[o] = sc[p];
-            float u, v;
-            if (a.fisheye) undistort_fisheye_dev(a, (float)x, (float)y, &u, &v);
-            else undistort_pinhole_dev(a, (float)x, (float)y, &u, &v);
-            a.kp_un[2 * o] = u;
-            a.kp_un[2 * o + 1] = v;
-            a.kp_out[o] = !(u >= 1 && u < a.W - 1 && v >= 1 && v < a.H - 1);
+    if (S <= EMIT_SORT_CAP) {
+        int P = 1;
+        while (P < S) P <<= 1;
+        for (int k = tid; k < P; k += 1024) skey[k] = k < S ? prio_key(sc[kept[k]], kept[k]) : 0ull;
+        __syncthreads();
+        // bitonic sort, descending
+        for (int size = 2; size <= P; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (P >> 1); t += 1024) {
+                    const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    const bool desc = (lo & size) == 0;
+                    const unsigned long long x = skey[lo], y = skey[hi];
+                    if ((x < y) == desc) { skey[lo] = y; skey[hi] = x; }
+                }
+                __syncthreads();
+            }
+        for (int r = tid; r < n; r += 1024) emit_point(a, b, sc, 0xFFFFFFFFu - (uint32_t)(skey[r] & 0xFFFFFFFFull), r);
+    } else {
+        unsigned long long* key = a.kept_key + (size_t)b * a.kept_cap;
+        for (int k = tid; k < S; k += 1024) key[k] = prio_key(sc[kept[k]], kept[k]);
+        __syncthreads();
+        for (int k = tid; k < S; k += 1024) {
+            const unsigned long long mine = key[k];
+            int rank = 0;
+            for (int j = 0; j < S; j++) rank += key[j] > mine;
+            if (rank < n) emit_point(a, b, sc, kept[k], rank);
         }
     }
-    if (threadIdx.x == 0) cnt[3] = n;
+    if (tid == 0) cnt[3] = n;
 }
 
 hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
@@ -1090,20 +1188,30 @@ __global__ __launch_bounds__(64) void match_init_resolve_kernel(MatchArgs a) {
     for (int k = lane; k < CLAIM_WORDS; k += 64) claimed[k] = 0;
     __syncthreads();
     int nmatches = 0;
+    // lists of the first group; each later group is fetched while the previous one is being resolved
+    float dv = 3e38f;
+    int iv = -1;
+    if ((lane >> 3) < nA) {
+        dv = a.topk_dist[lane];
+        iv = a.topk_idx[lane];
+    }
     for (int r0 = 0; r0 < nA; r0 += 8) {
-        // lane -> (row r0 + lane/8, entry lane%8): one coalesced 256-B read per array
-        float dv = 3e38f;
-        int iv = -1;
-        if (r0 + (lane >> 3) < nA) {
-            dv = a.topk_dist[(size_t)r0 * TOPK + lane];
-            iv = a.topk_idx[(size_t)r0 * TOPK + lane];
+        const float dcur = dv;
+        const int icur = iv;
+        dv = 3e38f;
+        iv = -1;
+        if (r0 + 8 + (lane >> 3) < nA) {  // lane -> (row r0 + 8 + lane/8, entry lane%8): one coalesced 256-B read per array
+            dv = a.topk_dist[(size_t)(r0 + 8) * TOPK + lane];
+            iv = a.topk_idx[(size_t)(r0 + 8) * TOPK + lane];
         }
         const int rows = min(8, nA - r0);
+        int om = -1;
+        float ob = 1e6f, os = 1e6f;  // results of row r0 + lane (lane < rows), stored once per group
         for (int rr = 0; rr < rows; rr++) {
             const int row = r0 + rr;
             const int srcl = rr * 8 + (lane & 7);
-            float d = __shfl(dv, srcl);
-            int idx = __shfl(iv, srcl);
+            float d = __shfl(dcur, srcl);
+            int idx = __shfl(icur, srcl);
             if (lane >= TOPK) { d = 3e38f; idx = -1; }
             const bool listed = idx >= 0;
             bool free_ = false;
@@ -1142,9 +1250,13 @@ __global__ __launch_bounds__(64) void match_init_resolve_kernel(MatchArgs a) {
                 nmatches++;
                 if (lane == 0) claimed[bidx >> 5] |= 1u << (bidx & 31);
             }
-            if (lane == 0) { a.match12[row] = m; a.best[row] = best; a.second[row] = second; }
-            __syncthreads();  // single wave: the claim is in LDS before the next row reads the bitmap
+            if (lane == rr) { om = m; ob = best; os = second; }
+            // One wave: its LDS operations execute in program order, so the claim above is in LDS before
+            // the next row's lanes read the bitmap; the fence only stops the compiler from reordering them.
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
+        if (lane < rows) { a.match12[r0 + lane] = om; a.best[r0 + lane] = ob; a.second[r0 + lane] = os; }
     }
     if (lane == 0) *a.n_matches = nmatches;
 }
