@@ -99,8 +99,8 @@ int ppg_extract_batch_device(ppg_ctx* ctx, const uint8_t* d_imgs, int n, ppg_fra
  * frame b of the previously submitted batch) plus the copies to pinned host memory, and returns without
  * waiting.  ppg_wait_batch blocks until the OLDEST submitted batch is on the host, finishes its line
  * graphs and fills outs (and matches12: n rows of junction_max_num entries; n_matches: n counts; both
- * optional).  It returns the batch's frame count (> 0) or a negative error.  At most three batches may be
- * in flight; the buffers behind `outs` stay valid until the third submit after this wait.
+ * optional).  It returns the batch's frame count (> 0) or a negative error.  At most four batches may be
+ * in flight; the buffers behind `outs` stay valid until the fourth submit after this wait.
  * No counterpart in the reference (PPGExtractor::run blocks, PPGExtractor.cpp:125). */
 int ppg_submit_batch_device(ppg_ctx* ctx, const uint8_t* d_imgs, int n, int match_prev, float nnratio);
 /* The same for host images (copied to pinned staging memory before the call returns). */
@@ -226,6 +226,8 @@ void* ppg_stream(ppg_ctx* ctx);
 #define PPG_PROF_N 10
 int ppg_profile(ppg_ctx* ctx, int enable);
 int ppg_profile_read(ppg_ctx* ctx, double* ms, long long* launches);
+/* Algorithmic FLOPs (2 x MACs of the layers' shapes) enqueued per class since ppg_profile(ctx, 1); conv classes only. */
+int ppg_profile_flops(ppg_ctx* ctx, double* flops);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,7 @@ def lib():
         L.ppg_wait_batch.argtypes = [C.c_void_p, C.POINTER(FrameOut), C.c_void_p, C.c_void_p]
         L.ppg_profile.argtypes = [C.c_void_p, C.c_int]
         L.ppg_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ppg_profile_flops.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -285,6 +286,9 @@ class Context:
         ms = (C.c_double * 10)()
         launches = (C.c_longlong * 10)()
         self._chk(self.L.ppg_profile_read(C.c_void_p(self.h), ms, launches))
+        fl = (C.c_double * 10)()
+        self._chk(self.L.ppg_profile_flops(C.c_void_p(self.h), fl))
+        self.last_profile_flops = {k: fl[i] for i, k in enumerate(("conv3x3", "conv_other", "conv1a"))}
         names = ("conv3x3", "conv_other", "conv1a", "post", "match", "host_wait", "host_tail", "host_submit", "host_finish", "host_tail_frames")
         return {k: (ms[i], launches[i]) for i, k in enumerate(names)}
 

@@ -40,11 +40,13 @@ struct DBuf {
     size_t n = 0;
 };
 
-// Everything a batch hands to the host lives kSlots times (a ring), so that three batches can be in
-// flight: one in the CNN, one in post-processing / matching / copy-out, one in the host's line-graph tail
+// Everything a batch hands to the host lives kSlots times (a ring), so that four batches can be in
+// flight: two in the CNN (one per lane), one in post-processing / matching / copy-out, one in the host's
+// line-graph tail
 // (ppg_submit_batch* / ppg_wait_batch).  The slot before the current one also is "the previous frame" of
 // every stream for frame-to-frame matching.
-constexpr int kSlots = 3;
+constexpr int kSlots = 4;
+constexpr int kLanes = 2;
 inline int next_slot(int s) { return (s + 1) % kSlots; }
 inline int prev_slot(int s) { return (s + kSlots - 1) % kSlots; }
 struct Slot {
@@ -75,6 +77,15 @@ struct Slot {
     bool matched = false;         // the submit included the match against the other slot
 };
 
+// The CNN intermediates and their stream exist twice: consecutive batches alternate between the two
+// lanes, so the work-groups of one batch's convolution fill the partially empty last rounds of the other's.
+struct Lane {
+    hipStream_t stream = nullptr;
+    uint8_t* d_img = nullptr;
+    float *a1 = nullptr, *p1 = nullptr, *a2 = nullptr, *p2 = nullptr, *a3 = nullptr, *p3 = nullptr, *a4 = nullptr,
+          *feat = nullptr, *pa_o = nullptr, *da_o = nullptr, *hs0 = nullptr, *hs1 = nullptr;
+};
+
 }  // namespace
 
 struct ppg_ctx {
@@ -82,12 +93,15 @@ struct ppg_ctx {
     std::string weights_path;
     std::string err;
     int W = 0, H = 0, w8 = 0, h8 = 0, B = 0, maxn = 0;
-    hipStream_t stream = nullptr;       // CNN: image upload and every convolution
+    Lane lane[kLanes];
+    int lane_cur = 0, nlanes = kLanes;
+    hipStream_t stream = nullptr;       // CNN: image upload and every convolution (alias of the current lane's)
     hipStream_t post = nullptr;         // everything after the CNN, matching, copies to the host
     hipStream_t copy_stream = nullptr;  // late copies of an already finished slot
     std::vector<void*> dev_allocs, host_allocs;
     // weights
     DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
+    DevConv c4a_n1, c4b_n1;  // the same layers packed for 32-cout blocks (finer work-groups for small grids)
     float *c1a_w = nullptr, *c1a_b = nullptr, *h3_w = nullptr, *h3_b = nullptr;
     float* heads_w = nullptr;  // packed weights of convPa | convDa | EdgeHeatmap block 0, concatenated
     // activations
@@ -120,6 +134,7 @@ struct ppg_ctx {
     int host_threads = 1;
     bool skip_score = false, skip_heat = false, skip_refine = false;
     bool unfused_conv1a = false;
+    int conv_nbuf = 1;
     int last_n = 0;
     // previous extract call's descriptors / counts stay resident for frame-to-frame matching
     float* desc_prev = nullptr;
@@ -132,6 +147,7 @@ struct ppg_ctx {
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pairs;
     double prof_ms[PPG_PROF_N] = {};
     long long prof_launches[PPG_PROF_N] = {};
+    double prof_flops[PPG_PROF_N] = {};  // algorithmic FLOPs enqueued per class while profiling
     // matcher scratch (grown on demand)
     DBuf<float> mA, mB, mD, mBest, mSecond, mTopD;
     DBuf<int32_t> mOff, mIdx, mMatch, mTopI;
@@ -213,6 +229,14 @@ void prof_resolve(ppg_ctx* c) {
         }
     }
     c->ev_pairs.resize(keep);
+}
+
+void select_lane(ppg_ctx* c, int li) {
+    Lane& l = c->lane[li];
+    c->lane_cur = li;
+    c->stream = l.stream; c->d_img = l.d_img;
+    c->a1 = l.a1; c->p1 = l.p1; c->a2 = l.a2; c->p2 = l.p2; c->a3 = l.a3; c->p3 = l.p3; c->a4 = l.a4;
+    c->feat = l.feat; c->pa_o = l.pa_o; c->da_o = l.da_o; c->hs0 = l.hs0; c->hs1 = l.hs1;
 }
 
 bool any_inflight(const ppg_ctx* c) {
@@ -380,6 +404,8 @@ int load_weights(ppg_ctx* c) {
     mk("backbone.conv3b", 2, false, "", c->c3b);
     mk("backbone.conv4a", 2, false, "", c->c4a);
     mk("backbone.conv4b", 2, false, "", c->c4b);
+    mk("backbone.conv4a", 1, false, "", c->c4a_n1);
+    mk("backbone.conv4b", 1, false, "", c->c4b_n1);
     mk("point.convPa", 2, false, "", c->pa);
     mk("point.convPb", 1, false, "", c->pb);
     mk("desc.convDa", 2, false, "", c->da);
@@ -422,6 +448,17 @@ int pick_tile(const DevConv& dc, int H, int W, int mode) {
     return a16 < a32 ? 16 : 32;
 }
 
+// Work-groups of a launch run in rounds of (CUs x resident blocks): 2 per CU for 64-cout blocks (LDS), 3 for
+// 32-cout blocks.  Pick the packing whose last round is fuller; a 32-cout block re-stages the same input
+// for half the MFMAs, hence the 0.9.
+const DevConv& pick_packing(const DevConv& n2, const DevConv& n1, int n, int H, int W) {
+    const int mw = pick_tile(n2, H, W, ppg::CONV_PLAIN);
+    const long tiles = (long)((W + mw - 1) / mw) * ((H + 256 / mw - 1) / (256 / mw)) * n;
+    const long b2 = tiles * n2.nblk, b1 = ((W + 31) / 32) * (long)((H + 7) / 8) * n * n1.nblk;
+    const double e2 = (double)b2 / (double)((b2 + 511) / 512 * 512), e1 = 0.9 * (double)b1 / (double)((b1 + 767) / 768 * 768);
+    return e1 > e2 ? n1 : n2;
+}
+
 ppg::ConvGroup conv_group(const DevConv& dc, float* out, int mode, int relu, int nblk0) {
     ppg::ConvGroup g;
     g.out = out; g.bias = dc.bias; g.alpha = dc.alpha; g.beta = dc.beta;
@@ -438,8 +475,11 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
     a.mw = fused_img ? 32 : pick_tile(dc, H, W, mode);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw); a.nblk = dc.nblk;
     a.ngroups = 1;
+    a.nbuf = c->conv_nbuf;
     a.g[0] = conv_group(dc, out, mode, relu, 0);
-    ProfScope ps(c, fused_img ? PPG_PROF_CONV1A : (dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER), c->stream);
+    const int cls = fused_img ? PPG_PROF_CONV1A : (dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER);
+    if (c->prof) c->prof_flops[cls] += 2.0 * n * H * W * (double)dc.cin * dc.cout * dc.ks * dc.ks + (fused_img ? 2.0 * n * H * W * 9.0 * 64 : 0.0);
+    ProfScope ps(c, cls, c->stream);
     HIPCHK(c, ppg::launch_conv(a, dc.ks, dc.nt, c->stream));
     return PPG_OK;
 }
@@ -454,9 +494,11 @@ int run_heads(ppg_ctx* c, int n, int H, int W) {
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
     a.nblk = c->pa.nblk + c->da.nblk + c->h0.nblk;
     a.ngroups = 3;
+    a.nbuf = c->conv_nbuf;
     a.g[0] = conv_group(c->pa, c->pa_o, ppg::CONV_PLAIN, 1, 0);
     a.g[1] = conv_group(c->da, c->da_o, ppg::CONV_PLAIN, 1, c->pa.nblk);
     a.g[2] = conv_group(c->h0, c->hs0, ppg::CONV_PS2, 1, c->pa.nblk + c->da.nblk);
+    if (c->prof) c->prof_flops[PPG_PROF_CONV3X3] += 2.0 * n * H * W * 9.0 * c->pa.cin * (c->pa.cout + c->da.cout + c->h0.cout);
     ProfScope ps(c, PPG_PROF_CONV3X3, c->stream);
     HIPCHK(c, ppg::launch_conv(a, 3, 2, c->stream));
     return PPG_OK;
@@ -532,7 +574,8 @@ const char* ppg_last_error(const ppg_ctx* c) { return c ? c->err.c_str() : g_err
 void ppg_destroy(ppg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Lane& l : c->lane)
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
     if (c->post) (void)hipStreamSynchronize(c->post);
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
@@ -545,7 +588,8 @@ void ppg_destroy(ppg_ctx* c) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.cnn_done) (void)hipEventDestroy(sl.cnn_done);
     }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (Lane& l : c->lane)
+        if (l.stream) (void)hipStreamDestroy(l.stream);
     if (c->post) (void)hipStreamDestroy(c->post);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -575,27 +619,47 @@ static int create_impl(ppg_ctx* c) {
     HIPCHK(c, hipGetDeviceProperties(&prop, f.device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, PPG_EHIP, "device %d is %s; this library is built for gfx950 only", f.device_id, prop.gcnArchName);
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->post, hipStreamNonBlocking));
+    // the MFMA-bound CNN gets dispatch priority; the latency-bound post-processing fills what is left
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    for (Lane& l : c->lane) HIPCHK(c, hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->post, hipStreamNonBlocking, prio_lo));
     HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    {
+        const char* u = getenv("PPG_UNFUSED_CONV1A");
+        c->unfused_conv1a = u && atoi(u) != 0;
+        const char* nbf = getenv("PPG_CONV_NBUF");
+        if (nbf && atoi(nbf) == 2) c->conv_nbuf = 2;
+        const char* nl = getenv("PPG_CNN_LANES");
+        if (nl && atoi(nl) == 1) c->nlanes = 1;
+        const char* e = getenv("PPG_HOST_THREADS");
+        int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        c->host_threads = std::max(1, std::min(t, 64));
+    }
     int rc = load_weights(c);
     if (rc) return rc;
     const size_t B = c->B, HW = (size_t)c->H * c->W, hw = (size_t)c->h8 * c->w8;
 #define DA(ptr, n) do { rc = dalloc(c, &c->ptr, (n)); if (rc) return rc; } while (0)
 #define HA(ptr, n) do { rc = halloc(c, &c->ptr, (n)); if (rc) return rc; } while (0)
-    DA(d_img, B * HW);
-    DA(a1, B * HW * 64);
-    DA(p1, B * HW / 4 * 64);
-    DA(a2, B * HW / 4 * 64);
-    DA(p2, B * HW / 16 * 64);
-    DA(a3, B * HW / 16 * 128);
-    DA(p3, B * hw * 128);
-    DA(a4, B * hw * 128);
-    DA(feat, B * hw * 128);
-    DA(pa_o, B * hw * 256);
-    DA(da_o, B * hw * 256);
-    DA(hs0, B * hw * 4 * 64);
-    DA(hs1, B * hw * 16 * 16);
+    for (int li = 0; li < c->nlanes; li++) {
+        Lane& l = c->lane[li];
+#define DL(ptr, n) do { rc = dalloc(c, &l.ptr, (n)); if (rc) return rc; } while (0)
+        DL(d_img, B * HW);
+        if (c->unfused_conv1a) DL(a1, B * HW * 64);
+        DL(p1, B * HW / 4 * 64);
+        DL(a2, B * HW / 4 * 64);
+        DL(p2, B * HW / 16 * 64);
+        DL(a3, B * HW / 16 * 128);
+        DL(p3, B * hw * 128);
+        DL(a4, B * hw * 128);
+        DL(feat, B * hw * 128);
+        DL(pa_o, B * hw * 256);
+        DL(da_o, B * hw * 256);
+        DL(hs0, B * hw * 4 * 64);
+        DL(hs1, B * hw * 16 * 16);
+#undef DL
+    }
+    select_lane(c, 0);
     DA(heat_raw, B * HW * 2);
     DA(prob, B * HW);
     DA(refined, B * HW);
@@ -650,13 +714,6 @@ static int create_impl(ppg_ctx* c) {
 #undef HA
     select_slot(c, 0);
     c->tails.resize(B);
-    {
-        const char* u = getenv("PPG_UNFUSED_CONV1A");
-        c->unfused_conv1a = u && atoi(u) != 0;
-        const char* e = getenv("PPG_HOST_THREADS");
-        int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-        c->host_threads = std::max(1, std::min(t, 64));
-    }
     // warm-up on an all-ones image, as the reference constructor does (PPGExtractor.cpp:100-106)
     // (at the full batch size, so that every kernel has run once at its production shape)
     std::vector<uint8_t> warm(HW, 1);
@@ -688,7 +745,7 @@ int ppg_read_tensor(ppg_ctx* c, int which, int frame, float* dst, size_t n) {
     const size_t e = tensor_elems(c, which);
     if (!e || !dst || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_read_tensor: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (Lane& l : c->lane) HIPCHK(c, hipStreamSynchronize(l.stream));
     HIPCHK(c, hipStreamSynchronize(c->post));
     HIPCHK(c, hipMemcpy(dst, tensor_ptr(c, which) + (size_t)frame * e, e * sizeof(float), hipMemcpyDeviceToHost));
     return PPG_OK;
@@ -699,7 +756,7 @@ int ppg_write_tensor(ppg_ctx* c, int which, int frame, const float* src, size_t 
     const size_t e = tensor_elems(c, which);
     if (!e || !src || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_write_tensor: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (Lane& l : c->lane) HIPCHK(c, hipStreamSynchronize(l.stream));
     HIPCHK(c, hipStreamSynchronize(c->post));
     HIPCHK(c, hipMemcpy(tensor_ptr(c, which) + (size_t)frame * e, src, e * sizeof(float), hipMemcpyHostToDevice));
     // an injected map replaces the one the next stage call would compute from the network outputs
@@ -718,7 +775,8 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     c->skip_score = c->skip_heat = c->skip_refine = false;
     {
         const int ns = next_slot(c->cur);
-        if (c->slot[ns].inflight) return fail(c, PPG_EINVAL, "three batches are in flight: call ppg_wait_batch first");
+        if (!c->slot[ns].inflight) select_lane(c, (c->lane_cur + 1) % c->nlanes);
+        if (c->slot[ns].inflight) return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
         select_slot(c, ns);
         c->slot[ns].n = n;
         c->slot[ns].matched = false;
@@ -748,8 +806,8 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     RC(run_conv(c, c->c2b, c->a2, c->p2, n, H / 2, W / 2, ppg::CONV_POOL2, 1));
     RC(run_conv(c, c->c3a, c->p2, c->a3, n, H / 4, W / 4, ppg::CONV_PLAIN, 1));
     RC(run_conv(c, c->c3b, c->a3, c->p3, n, H / 4, W / 4, ppg::CONV_POOL2, 1));
-    RC(run_conv(c, c->c4a, c->p3, c->a4, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
-    RC(run_conv(c, c->c4b, c->a4, c->feat, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, pick_packing(c->c4a, c->c4a_n1, n, H / 8, W / 8), c->p3, c->a4, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, pick_packing(c->c4b, c->c4b_n1, n, H / 8, W / 8), c->a4, c->feat, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
     // PointHeatmap (junction_decoder.py:14-15)
     RC(run_heads(c, n, H / 8, W / 8));  // convPa + convDa + EdgeHeatmap block 0
     RC(run_conv(c, c->pb, c->pa_o, c->junc, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
@@ -1020,7 +1078,7 @@ static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int 
     if (!imgs || n < 1 || n > c->B || row_stride < c->W)
         return fail(c, PPG_EINVAL, "bad image batch (n = %d, max_batch = %d, row_stride = %d)", n, c->B, row_stride);
     Slot& nx = c->slot[next_slot(c->cur)];
-    if (nx.inflight) return fail(c, PPG_EINVAL, "three batches are in flight: call ppg_wait_batch first");
+    if (nx.inflight) return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
     const size_t HW = (size_t)c->H * c->W;
     for (int b = 0; b < n; b++) {
         if (!imgs[b]) return fail(c, PPG_EINVAL, "image %d is NULL", b);
@@ -1329,7 +1387,13 @@ int ppg_match_prev_batch(ppg_ctx* c, int n, float nnratio, int32_t* m12, int* n_
 int ppg_profile(ppg_ctx* c, int enable) {
     if (!c) return PPG_EINVAL;
     c->prof = enable != 0;
-    for (int k = 0; k < PPG_PROF_N; k++) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; }
+    for (int k = 0; k < PPG_PROF_N; k++) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_flops[k] = 0; }
+    return PPG_OK;
+}
+
+int ppg_profile_flops(ppg_ctx* c, double* flops) {
+    if (!c || !flops) return PPG_EINVAL;
+    for (int k = 0; k < PPG_PROF_N; k++) flops[k] = c->prof_flops[k];
     return PPG_OK;
 }
 

@@ -36,8 +36,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Two tile shapes (MW = width of one 32-pixel M tile): MW = 32 -> 8 rows x 32 columns per work-group (an M
 // tile is one row segment), MW = 16 -> 16 x 16 (an M tile is 2 rows x 16 columns), which wastes less of
 // feature maps whose width is a multiple of 16 but not of 32 (e.g. 80 columns at 640/8).
-template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32, int NBUF = 2>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
     constexpr int TW = MW, TH = 256 / MW;
     constexpr int PAD = KS / 2;
     constexpr int IH = TH + KS - 1, IW = TW + KS - 1, IN_PIX = IH * IW;
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     // the tile (two halo rings) instead of being read from memory: patch as floats + conv1a weights.
     constexpr int PH = IH + 2, PW = IW + 2;
     constexpr int FUSE_FLOATS = FUSE1A ? (PH * PW + 9 * 64 + 64) : 0;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF + FUSE_FLOATS];
-    float* patch = smem + 2 * BUF;           // [PH][PW]
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF + FUSE_FLOATS];
+    float* patch = smem + NBUF * BUF;        // [PH][PW]
     float* w1s = patch + PH * PW;            // [9][64]
     float* b1s = w1s + 9 * 64;               // [64]
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     stash(0);
     __syncthreads();
     for (int c = 0; c < nchunks; c++) {
-        const int buf = c & 1;
+        const int buf = NBUF == 2 ? (c & 1) : 0;
         if (c + 1 < nchunks) fetch(c + 1);
         const float* ins = smem + buf * BUF;
         const float* ws = ins + IN_FLOATS;
@@ -189,8 +189,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
             }
         }
-        if (c + 1 < nchunks) stash(buf ^ 1);
-        __syncthreads();
+        if (NBUF == 2) {
+            if (c + 1 < nchunks) stash(buf ^ 1);
+            __syncthreads();
+        } else {
+            // one LDS buffer (three work-groups per CU instead of two): everybody must be done reading
+            // the chunk before it is overwritten
+            __syncthreads();
+            if (c + 1 < nchunks) stash(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store ----
@@ -254,8 +262,11 @@ int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
 hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
     if (a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
-    if (ks == 3 && nt == 2 && a.img) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true>), grid, block, 0, s, a);
+    if (ks == 3 && nt == 2 && a.img && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true, 32, 1>), grid, block, 0, s, a);
+    else if (ks == 3 && nt == 2 && a.img) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true>), grid, block, 0, s, a);
+    else if (ks == 3 && nt == 2 && a.mw == 16 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16, 1>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2 && a.mw == 16) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16>), grid, block, 0, s, a);
+    else if (ks == 3 && nt == 2 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 32, 1>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8>), grid, block, 0, s, a);
     else if (ks == 1 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 16>), grid, block, 0, s, a);

@@ -299,7 +299,7 @@ def test_match_prev_batch_resident(pkg, orc, synth):
 
 
 def test_pipelined_submit_wait_equals_blocking(pkg, synth):
-    """Three batches in flight: results (frames and matches) must equal the blocking calls bit for bit."""
+    """Four batches in flight: results (frames and matches) must equal the blocking calls bit for bit."""
     H, W = 96, 128
     ctx = get_ctx(pkg, W, H, 500, batch=4)
     seqs = [[synth.make_frame(H, W, s, t, k) for s, k in ((1, "sparse"), (7, "dense"), (3, "sparse"))] for t in range(4)]
@@ -310,16 +310,15 @@ def test_pipelined_submit_wait_equals_blocking(pkg, synth):
             ref_matches.append(ctx.match_prev_batch(3, 0.9))
     got = []
     ctx.submit_batch(seqs[0], match_prev=False)
-    ctx.submit_batch(seqs[1], match_prev=True)
-    for t in range(2, 4):
-        ctx.submit_batch(seqs[t], match_prev=True)  # three batches in flight
-        with pytest.raises(pkg.PPGError, match="in flight"):
-            ctx.submit_batch(seqs[t])
-        with pytest.raises(pkg.PPGError, match="pending"):
-            ctx.extract(seqs[t][0])
+    for t in range(1, 4):
+        ctx.submit_batch(seqs[t], match_prev=True)
+    # four batches in flight: the ring is full
+    with pytest.raises(pkg.PPGError, match="in flight"):
+        ctx.submit_batch(seqs[0])
+    with pytest.raises(pkg.PPGError, match="pending"):
+        ctx.extract(seqs[0][0])
+    for t in range(4):
         got.append(ctx.wait_batch())
-    got.append(ctx.wait_batch())
-    got.append(ctx.wait_batch())
     with pytest.raises(pkg.PPGError, match="nothing was submitted"):
         ctx.wait_batch()
     for t in range(4):
