@@ -1,0 +1,97 @@
+// Isolated timing of the convolution kernel on the layer shapes of the 640x480 front-end (batch 16).
+// Build with -DPPG_UB=<mask> to knock out parts of the kernel (1 stores, 2 fused conv1a arithmetic,
+// 4 stash + barriers, 8 fetch) and see what each costs.  Results are NOT meaningful with a mask.
+#ifndef PPG_UB
+#define PPG_UB 0
+#endif
+#ifdef TRACE
+#include "k_trace.hip"
+#else
+#include "../../ppg-slam_amd/csrc/ppg_kernels.hip"
+#endif
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace ppg;
+__global__ void clock_probe(long long* out, long long wall_ticks) {
+    const long long c0 = clock64(), w0 = wall_clock64();
+    while (wall_clock64() - w0 < wall_ticks) __builtin_amdgcn_s_sleep(64);
+    out[0] = clock64() - c0;
+    out[1] = wall_clock64() - w0;
+}
+__global__ void fill_rand(float* p, size_t n, float scale) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = ((int)(x & 0xffff) - 32768) * (scale / 32768.f);
+    }
+}
+__global__ void fill_rand8(uint8_t* p, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; p[i] = (uint8_t)x; }
+}
+struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, nbuf; };
+int main(int argc, char** argv) {
+    const int B = 16;
+    std::vector<L> ls = {
+        {"conv1b fused pool", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 1},
+        {"conv1b fused pool nbuf2", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 2},
+        {"conv2a plain", 240, 320, 64, 64, CONV_PLAIN, 0, 32, 2, 1},
+        {"conv2b pool", 240, 320, 64, 64, CONV_POOL2, 0, 32, 2, 1},
+        {"conv3a plain", 120, 160, 64, 128, CONV_PLAIN, 0, 32, 2, 1},
+        {"conv3b pool", 120, 160, 128, 128, CONV_POOL2, 0, 32, 2, 1},
+        {"conv4a plain nt1", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 1, 2},
+        {"conv4a plain mw16", 60, 80, 128, 128, CONV_PLAIN, 0, 16, 2, 1},
+        {"heads 768 mw16", 60, 80, 128, 768, CONV_PLAIN, 0, 16, 2, 1},
+    };
+    size_t maxin = (size_t)B * 480 * 640 * 64;
+    float *din, *dout, *dw, *dbias; uint8_t* dimg;
+    hipMalloc(&din, maxin * 4 / 4); hipMalloc(&dout, maxin * 4); hipMalloc(&dw, 16 << 20); hipMalloc(&dbias, 4096);
+    hipMalloc(&dimg, (size_t)B * 480 * 640);
+    hipMemset(din, 0, maxin); hipMemset(dw, 0, 16 << 20); hipMemset(dbias, 0, 4096); hipMemset(dimg, 7, (size_t)B * 480 * 640);
+    const bool rnd = argc > 1 && atoi(argv[1]) == 1;
+    if (rnd) {
+        fill_rand<<<4096, 256>>>(din, maxin / 4, 1.f);
+        fill_rand<<<4096, 256>>>(dw, (16 << 20) / 4, 0.05f);
+        fill_rand8<<<4096, 256>>>(dimg, (size_t)B * 480 * 640);
+        hipDeviceSynchronize();
+    }
+    hipStream_t s2; hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    long long* dclk; hipMalloc(&dclk, 16); long long hclk[2];
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (const L& l : ls) {
+        ConvArgs a{};
+        a.in = din; a.wpk = dw; a.B = B; a.H = l.H; a.W = l.W; a.Cin = l.Cin;
+        if (l.fused) { a.img = dimg; a.w1a = dw; a.b1a = dbias; }
+        const int tw = l.mw, th = 256 / l.mw;
+        a.tiles_x = (l.W + tw - 1) / tw; a.tiles_y = (l.H + th - 1) / th; a.nblk = l.Cout / (32 * l.nt);
+        a.mw = l.mw; a.nbuf = l.nbuf; a.ngroups = 1;
+        a.g[0].out = dout; a.g[0].bias = dbias; a.g[0].nblk0 = 0; a.g[0].Cout = l.Cout; a.g[0].mode = l.mode; a.g[0].relu = 1;
+        for (int i = 0; i < 3; i++) launch_conv(a, 3, l.nt, 0);
+        hipDeviceSynchronize();
+        const int reps = 10;
+        float est; { hipEventRecord(e0); launch_conv(a, 3, l.nt, 0); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&est, e0, e1); }
+        hipEventRecord(e0);
+        clock_probe<<<1, 64, 0, s2>>>(dclk, (long long)(est * reps * 0.8 * 1e5));
+        for (int i = 0; i < reps; i++) if (launch_conv(a, 3, l.nt, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+        double fl = 2.0 * B * l.H * l.W * l.Cin * l.Cout * 9;
+        hipStreamSynchronize(s2);
+        hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost);
+#ifdef TRACE
+        if (&l == &ls[0] || &l == &ls[3]) {
+            const int nb = a.tiles_x * a.tiles_y * B; std::vector<unsigned long long> h(4 * 32768);
+            hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_rec), h.size() * 8);
+            char fn[64]; snprintf(fn, sizeof fn, "../../gpurun_out/wgtrace_%d.txt", (int)(&l - &ls[0]));
+            FILE* f = fopen(fn, "w");
+            for (int i = 0; i < nb && i < 32768; i++) fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4*i], h[4*i+1], h[4*i+2], h[4*i+3]);
+            fclose(f);
+        }
+#endif
+        printf("UB=%d rnd=%d %-26s %8.1f us  %6.1f TF/s  blocks=%d  clk=%.0f MHz\n", PPG_UB, (int)rnd, l.name, ms * 1e3, fl / ms / 1e9,
+               a.tiles_x * a.tiles_y * B * a.nblk, 100.0 * hclk[0] / hclk[1]);
+    }
+    return 0;
+}

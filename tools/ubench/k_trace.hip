@@ -5,12 +5,13 @@
 // (keypoints, line candidates, match indices) agree bit for bit with a strict-IEEE CPU evaluation of
 // the reference's formulas.
 #include "ppg_kernels.h"
+__device__ unsigned long long g_rec[4 * 32768];
+
 
 #include <math.h>
 
 namespace ppg {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -52,11 +53,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
     constexpr int IN_PER_T = (IN_ITEMS + 255) / 256;
     constexpr int W_ITEMS = W_FLOATS / 4;
     constexpr int W_PER_T = (W_ITEMS + 255) / 256;
-    // every thread fills IN_PER_T input slots and W_PER_T weight slots without a branch: the slots past the end
-    // of the tile land in padding
-    constexpr int IN_FLOATS_P = (IN_PER_T * 256 / QPP) * PSTR;
-    constexpr int W_FLOATS_P = W_PER_T * 256 * 4;
-    constexpr int BUF = IN_FLOATS_P + W_FLOATS_P;
+    constexpr int BUF = IN_FLOATS + W_FLOATS;
     // FUSE1A: the input of this layer is conv1a(image) and is computed on the fly from the u8 patch of
     // the tile (two halo rings) instead of being read from memory: patch as floats + conv1a weights.
     constexpr int PH = IH + 2, PW = IW + 2;
@@ -76,27 +73,22 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
     auto prow = [&](int m, int i) { return MW == 32 ? 2 * wave + m : 4 * wave + 2 * m + (i >> 4); };
     auto pcol = [&](int i) { return MW == 32 ? i : (i & 15); };
 
-    // Byte offset of each fetch slot inside the image (FUSE1A: float offset inside the patch).  Padding pixels
-    // and slots past the tile get an offset no buffer contains, for which a buffer load returns zeros.
-    constexpr unsigned NOWHERE = 0xfffffff0u;
-    unsigned gofs[IN_PER_T];
+    long gofs[IN_PER_T];  // FUSE1A: >= 0 means "inside the image"; the value is the patch offset of the pixel
     int lofs[IN_PER_T];
 #pragma unroll
     for (int k = 0; k < IN_PER_T; k++) {
         const int item = tid + 256 * k;
-        const int pix = item / QPP, q = item % QPP;
-        const int py = pix / IW, px = pix % IW;
-        const int gy = y0 + py - PAD, gx = x0 + px - PAD;
-        lofs[k] = pix * PSTR + q * 4;
-        gofs[k] = NOWHERE;
-        if (item < IN_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            gofs[k] = FUSE1A ? (unsigned)(py * PW + px) : (unsigned)(((gy * a.W + gx) * a.Cin + q * 4) * 4);
+        gofs[k] = -1;
+        lofs[k] = -1;
+        if (item < IN_ITEMS) {
+            const int pix = item / QPP, q = item % QPP;
+            const int py = pix / IW, px = pix % IW;
+            const int gy = y0 + py - PAD, gx = x0 + px - PAD;
+            lofs[k] = pix * PSTR + q * 4;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                gofs[k] = FUSE1A ? (long)(py * PW + px) : ((long)(b * a.H + gy) * a.W + gx) * a.Cin + q * 4;
+        }
     }
-    // image b of the input and the packed weights of cout block nb, as buffers
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.in + (FUSE1A ? 0 : (size_t)b * a.H * a.W * a.Cin)), 0, FUSE1A ? 0 : a.H * a.W * a.Cin * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.wpk + (size_t)nb * nchunks * W_FLOATS), 0, nchunks * W_FLOATS * 4, 0x00020000);
     if (FUSE1A) {
         // patch pixel (py, px) = image pixel (y0 - 2 + py, x0 - 2 + px); u8 -> f32 by a true division
         // (feature/src/PPGExtractor.cpp:151), zero outside the image (conv1a's own zero padding)
@@ -111,52 +103,55 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
         if (tid < 64) b1s[tid] = a.b1a[tid];
         __syncthreads();
     }
+    const float* wsrc = a.wpk + (size_t)nb * nchunks * W_FLOATS;
 
     f32x4 vin[IN_PER_T], vw[W_PER_T];
     auto fetch = [&](int c) {
-        // slots past the chunk read the next chunk's weights (or zeros past the last one) into padding
 #pragma unroll
-        for (int k = 0; k < W_PER_T; k++)
-            vw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + 256 * k) * 16, c * W_FLOATS * 4, 0));
-        if (!FUSE1A) {
-#pragma unroll
-            for (int k = 0; k < IN_PER_T; k++)
-                vin[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, gofs[k], c * KC * 4, 0));
-        } else {
-            // conv1a + ReLU for 4 channels of one pixel: bias, then the nine taps in (ky, kx) order, fmaf
-            // (backbone.py:28) — the same chain as conv1a_kernel, two channels per packed FMA.  All slots of
-            // a thread serve the same 4 channels.  Pixels outside the image are this layer's zero padding.
-            const int ch = c * KC + (tid % QPP) * 4;
-            const f32x4 bias = *(const f32x4*)(b1s + ch);
-            f32x4 w9[9];
-#pragma unroll
-            for (int t = 0; t < 9; t++) w9[t] = *(const f32x4*)(w1s + t * 64 + ch);
-#pragma unroll
-            for (int k = 0; k < IN_PER_T; k++) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < IN_PER_T; k++) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (!FUSE1A) {
+                vin[k] = gofs[k] >= 0 ? *(const f32x4*)(a.in + gofs[k] + c * KC) : z;
+            } else {
+                // conv1a + ReLU for 4 channels of one pixel: bias, then the nine taps in (ky, kx) order, fmaf
+                // (backbone.py:28) — the same chain as conv1a_kernel.  Pixels outside the image are this
+                // layer's zero padding.
                 vin[k] = z;
-                if (gofs[k] != NOWHERE) {
+                if (gofs[k] >= 0) {
+                    const int ch = c * KC + ((tid + 256 * k) % QPP) * 4;
+                    f32x4 acc = *(const f32x4*)(b1s + ch);
                     const float* pp = patch + gofs[k];
-                    f32x2 lo = {bias[0], bias[1]}, hi = {bias[2], bias[3]};
 #pragma unroll
                     for (int t = 0; t < 9; t++) {
                         const float v = pp[(t / 3) * PW + (t % 3)];
-                        const f32x2 vv = {v, v};
-                        lo = __builtin_elementwise_fma(vv, (f32x2){w9[t][0], w9[t][1]}, lo);
-                        hi = __builtin_elementwise_fma(vv, (f32x2){w9[t][2], w9[t][3]}, hi);
+                        const f32x4 w = *(const f32x4*)(w1s + t * 64 + ch);
+                        acc[0] = fmaf(v, w[0], acc[0]); acc[1] = fmaf(v, w[1], acc[1]);
+                        acc[2] = fmaf(v, w[2], acc[2]); acc[3] = fmaf(v, w[3], acc[3]);
                     }
-                    vin[k] = (f32x4){fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f), fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
+                    acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f);
+                    acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f);
+                    vin[k] = acc;
                 }
             }
+        }
+#pragma unroll
+        for (int k = 0; k < W_PER_T; k++) {
+            const int item = tid + 256 * k;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            vw[k] = item < W_ITEMS ? *(const f32x4*)(wsrc + (size_t)c * W_FLOATS + item * 4) : z;
         }
     };
     auto stash = [&](int buf) {
         float* ins = smem + buf * BUF;
-        float* ws = ins + IN_FLOATS_P;
+        float* ws = ins + IN_FLOATS;
 #pragma unroll
-        for (int k = 0; k < IN_PER_T; k++) *(f32x4*)(ins + lofs[k]) = vin[k];
+        for (int k = 0; k < IN_PER_T; k++)
+            if (lofs[k] >= 0) *(f32x4*)(ins + lofs[k]) = vin[k];
 #pragma unroll
-        for (int k = 0; k < W_PER_T; k++) *(f32x4*)(ws + (tid + 256 * k) * 4) = vw[k];
+        for (int k = 0; k < W_PER_T; k++) {
+            const int item = tid + 256 * k;
+            if (item < W_ITEMS) *(f32x4*)(ws + item * 4) = vw[k];
+        }
     };
 
     f32x16 acc[2][NT];
@@ -167,6 +162,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
+    // Issue slots of a SIMD go to the wave with the higher priority, then to the older one.  The staging
+    // phases are short and everything downstream waits for them, so they run at high priority and steal
+    // the few slots they need from whichever wave is streaming MFMAs (priority 0).
+    const unsigned long long w_start = wall_clock64();
     fetch(0);
     stash(0);
     __syncthreads();
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
         const int buf = NBUF == 2 ? (c & 1) : 0;
         if (c + 1 < nchunks) fetch(c + 1);
         const float* ins = smem + buf * BUF;
-        const float* ws = ins + IN_FLOATS_P;
+        const float* ws = ins + IN_FLOATS;
 #pragma unroll
         for (int g = 0; g < KC / 8; g++) {
 #pragma unroll
@@ -262,6 +261,14 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
             }
         }
     }
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 32768) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));     // HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));   // XCC_ID
+        g_rec[4 * blockIdx.x + 0] = hw;
+        g_rec[4 * blockIdx.x + 1] = xcc;
+        g_rec[4 * blockIdx.x + 2] = w_start;
+        g_rec[4 * blockIdx.x + 3] = wall_clock64();
+    }
 }
 
 int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
@@ -269,8 +276,6 @@ int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
 hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
     if (a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
-    // one image of the input is addressed as a buffer with 32-bit byte offsets
-    if ((long)a.H * a.W * a.Cin * 4 > 0x7fffffffL) return hipErrorInvalidValue;
     if (ks == 3 && nt == 2 && a.img && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true, 32, 1>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2 && a.img) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2 && a.mw == 16 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16, 1>), grid, block, 0, s, a);
