@@ -94,14 +94,13 @@ struct ppg_ctx {
     std::string err;
     int W = 0, H = 0, w8 = 0, h8 = 0, B = 0, maxn = 0;
     Lane lane[kLanes];
-    int lane_cur = 0, nlanes = kLanes;
+    int lane_cur = 0, nlanes = 1;  // PPG_CNN_LANES=2 alternates consecutive batches between two CNN streams
     hipStream_t stream = nullptr;       // CNN: image upload and every convolution (alias of the current lane's)
     hipStream_t post = nullptr;         // everything after the CNN, matching, copies to the host
     hipStream_t copy_stream = nullptr;  // late copies of an already finished slot
     std::vector<void*> dev_allocs, host_allocs;
     // weights
     DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
-    DevConv c4a_n1, c4b_n1;  // the same layers packed for 32-cout blocks (finer work-groups for small grids)
     float *c1a_w = nullptr, *c1a_b = nullptr, *h3_w = nullptr, *h3_b = nullptr;
     float* heads_w = nullptr;  // packed weights of convPa | convDa | EdgeHeatmap block 0, concatenated
     // activations
@@ -404,8 +403,6 @@ int load_weights(ppg_ctx* c) {
     mk("backbone.conv3b", 2, false, "", c->c3b);
     mk("backbone.conv4a", 2, false, "", c->c4a);
     mk("backbone.conv4b", 2, false, "", c->c4b);
-    mk("backbone.conv4a", 1, false, "", c->c4a_n1);
-    mk("backbone.conv4b", 1, false, "", c->c4b_n1);
     mk("point.convPa", 2, false, "", c->pa);
     mk("point.convPb", 1, false, "", c->pb);
     mk("desc.convDa", 2, false, "", c->da);
@@ -446,17 +443,6 @@ int pick_tile(const DevConv& dc, int H, int W, int mode) {
     if (dc.ks != 3 || dc.nt != 2 || mode == ppg::CONV_POOL2) return 32;
     const long a32 = (long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32), a16 = (long)((H + 15) / 16 * 16) * ((W + 15) / 16 * 16);
     return a16 < a32 ? 16 : 32;
-}
-
-// Work-groups of a launch run in rounds of (CUs x resident blocks): 2 per CU for 64-cout blocks (LDS), 3 for
-// 32-cout blocks.  Pick the packing whose last round is fuller; a 32-cout block re-stages the same input
-// for half the MFMAs, hence the 0.9.
-const DevConv& pick_packing(const DevConv& n2, const DevConv& n1, int n, int H, int W) {
-    const int mw = pick_tile(n2, H, W, ppg::CONV_PLAIN);
-    const long tiles = (long)((W + mw - 1) / mw) * ((H + 256 / mw - 1) / (256 / mw)) * n;
-    const long b2 = tiles * n2.nblk, b1 = ((W + 31) / 32) * (long)((H + 7) / 8) * n * n1.nblk;
-    const double e2 = (double)b2 / (double)((b2 + 511) / 512 * 512), e1 = 0.9 * (double)b1 / (double)((b1 + 767) / 768 * 768);
-    return e1 > e2 ? n1 : n2;
 }
 
 ppg::ConvGroup conv_group(const DevConv& dc, float* out, int mode, int relu, int nblk0) {
@@ -631,7 +617,7 @@ static int create_impl(ppg_ctx* c) {
         const char* nbf = getenv("PPG_CONV_NBUF");
         if (nbf && atoi(nbf) == 2) c->conv_nbuf = 2;
         const char* nl = getenv("PPG_CNN_LANES");
-        if (nl && atoi(nl) == 1) c->nlanes = 1;
+        if (nl && atoi(nl) == 2) c->nlanes = 2;
         const char* e = getenv("PPG_HOST_THREADS");
         int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         c->host_threads = std::max(1, std::min(t, 64));
@@ -806,8 +792,8 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     RC(run_conv(c, c->c2b, c->a2, c->p2, n, H / 2, W / 2, ppg::CONV_POOL2, 1));
     RC(run_conv(c, c->c3a, c->p2, c->a3, n, H / 4, W / 4, ppg::CONV_PLAIN, 1));
     RC(run_conv(c, c->c3b, c->a3, c->p3, n, H / 4, W / 4, ppg::CONV_POOL2, 1));
-    RC(run_conv(c, pick_packing(c->c4a, c->c4a_n1, n, H / 8, W / 8), c->p3, c->a4, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
-    RC(run_conv(c, pick_packing(c->c4b, c->c4b_n1, n, H / 8, W / 8), c->a4, c->feat, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, c->c4a, c->p3, c->a4, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
+    RC(run_conv(c, c->c4b, c->a4, c->feat, n, H / 8, W / 8, ppg::CONV_PLAIN, 1));
     // PointHeatmap (junction_decoder.py:14-15)
     RC(run_heads(c, n, H / 8, W / 8));  // convPa + convDa + EdgeHeatmap block 0
     RC(run_conv(c, c->pb, c->pa_o, c->junc, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));

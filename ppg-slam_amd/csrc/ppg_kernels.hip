@@ -25,10 +25,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //
 // Work-group = 4 waves, output tile 8 rows x 32 columns x NB couts (NB = 32*NT).
 // Wave w owns rows 2w, 2w+1 (two 32-pixel M tiles) x NT 32-cout N tiles.
-//   A operand (lane l): pixel x = l&31 of the row, cin = 4*(l>>5)+s for the s-th MFMA of a group
-//   B operand (lane l): cout = l&31,               same cin
-//   D: lane holds cout l&31; register r holds pixel x = (r&3) + 8*(r>>2) + 4*(l>>5)
-// so the 2x2 max-pool needs no cross-lane traffic: vertical = the two M tiles, horizontal = register pairs.
+//   A operand (lane l): cout = l&31,                 cin = 4*(l>>5)+s for the s-th MFMA of a group
+//   B operand (lane l): pixel x = l&31 of the row,   same cin
+//   D: lane holds pixel l&31; register r holds cout (r&3) + 8*(r>>2) + 4*(l>>5)
+// so a lane stores runs of four consecutive couts (16 bytes of the channels-last output), and the 2x2
+// max-pool is: vertical = the two pixel tiles, horizontal = the neighbouring lane (one DPP move).
 // Input is streamed through LDS in chunks of KC input channels (pixel stride KC+4 floats keeps the
 // 16-byte fragment reads of a 16-lane group on distinct banks); weights arrive pre-packed in
 // exactly the LDS image order.  Two LDS buffers: the next chunk is fetched into registers before the
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
                     for (int m = 0; m < 2; m++)
 #pragma unroll
                         for (int n = 0; n < NT; n++)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[n][s], av[m][s], acc[m][n], 0, 0, 0);
             }
         }
         if (NBUF == 2) {
@@ -209,55 +210,70 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
     }
 
     // ---- epilogue: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store ----
-    // A launch may serve up to three layers that read the same input (cout blocks [nblk0, next nblk0) each)
+    // A launch may serve up to three layers that read the same input (cout blocks [nblk0, next nblk0) each).
+    // The lane owns one pixel of each pixel tile and, per cout tile, four runs of four consecutive couts
+    // (registers 4j..4j+3 = couts 8j + 4*(l>>5) + 0..3): one 16-byte store per run.
     int gi = 0;
     if (a.ngroups > 1 && nb >= a.g[1].nblk0) gi = 1;
     if (a.ngroups > 2 && nb >= a.g[2].nblk0) gi = 2;
     const ConvGroup G = a.g[gi];
+    const int cb = (nb - G.nblk0) * NB;  // first cout of this block inside its layer (packed order)
+    const bool bn = G.alpha != nullptr;
+    const bool vec = (G.Cout & 3) == 0;  // rows of the output are 16-byte aligned
+    const int Cps = G.Cout >> 2;
 #pragma unroll
     for (int n = 0; n < NT; n++) {
-        const int co = (nb - G.nblk0) * NB + n * 32 + li;  // cout inside this layer (packed order)
-        const float bias = G.bias[co];
-        float al = 1.f, be = 0.f;
-        const bool bn = G.alpha != nullptr;
-        if (bn) { al = G.alpha[co]; be = G.beta[co]; }
-        if (co >= G.Cout) continue;
-        if (G.mode == CONV_POOL2) {
-            if (MW != 32) continue;  // pooled layers always use the 8 x 32 tile
-            const int yrow = y0 + 2 * wave;
-            const int Hp = a.H / 2, Wp = a.W / 2;
-            if (yrow + 1 < a.H) {
 #pragma unroll
-                for (int rp = 0; rp < 8; rp++) {
-                    const int r0 = 2 * rp;
-                    const int x = x0 + (r0 & 3) + 8 * (r0 >> 2) + 4 * lh;
-                    if (x + 1 < a.W) {
-                        float v = fmaxf(fmaxf(acc[0][n][r0], acc[0][n][r0 + 1]), fmaxf(acc[1][n][r0], acc[1][n][r0 + 1]));
-                        v = v + bias;
-                        if (G.relu) v = fmaxf(v, 0.f);
-                        G.out[((size_t)(b * Hp + (yrow >> 1)) * Wp + (x >> 1)) * G.Cout + co] = v;
-                    }
+        for (int j = 0; j < 4; j++) {
+            const int co = cb + n * 32 + 8 * j + 4 * lh;  // first of the four couts
+            if (co >= G.Cout) continue;
+            const f32x4 bias = *(const f32x4*)(G.bias + co);
+            f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+            if (bn) { al = *(const f32x4*)(G.alpha + co); be = *(const f32x4*)(G.beta + co); }
+            if (G.mode == CONV_POOL2) {
+                if (MW != 32) continue;  // pooled layers always use the 8 x 32 tile
+                // rows 2*wave, 2*wave+1 are the two pixel tiles; the column neighbour is the next lane
+                const int y = y0 + 2 * wave, x = x0 + li;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float t = fmaxf(acc[0][n][4 * j + e], acc[1][n][4 * j + e]);
+                    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+                    float r = fmaxf(t, o) + bias[e];
+                    if (G.relu) r = fmaxf(r, 0.f);
+                    v[e] = r;
                 }
-            }
-        } else {
+                if ((li & 1) == 0 && y + 1 < a.H && x + 1 < a.W) {
+                    float* dst = G.out + ((size_t)(b * (a.H / 2) + (y >> 1)) * (a.W / 2) + (x >> 1)) * G.Cout + co;
+                    if (vec) *(f32x4*)dst = v;
+                    else
+                        for (int e = 0; e < 4; e++)
+                            if (co + e < G.Cout) dst[e] = v[e];
+                }
+            } else {
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int y = y0 + prow(m, i), x = x0 + pcol(i);
+                for (int m = 0; m < 2; m++) {
+                    const int y = y0 + prow(m, li), x = x0 + pcol(li);
                     if (y >= a.H || x >= a.W) continue;
-                    float v = acc[m][n][r] + bias;
-                    if (bn) v = v * al + be;
-                    if (G.relu) v = fmaxf(v, 0.f);
-                    if (G.mode == CONV_PLAIN) {
-                        G.out[((size_t)(b * a.H + y) * a.W + x) * G.Cout + co] = v;
-                    } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx
-                        const int Cps = G.Cout >> 2;
-                        const int q = co / Cps, cc = co - q * Cps;
-                        const int Y = 2 * y + (q >> 1), X = 2 * x + (q & 1);
-                        G.out[((size_t)(b * 2 * a.H + Y) * (2 * a.W) + X) * Cps + cc] = v;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float r = acc[m][n][4 * j + e] + bias[e];
+                        if (bn) r = r * al[e] + be[e];
+                        if (G.relu) r = fmaxf(r, 0.f);
+                        v[e] = r;
                     }
+                    float* dst;
+                    if (G.mode == CONV_PLAIN) {
+                        dst = G.out + ((size_t)(b * a.H + y) * a.W + x) * G.Cout + co;
+                    } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx; Cps is a multiple of 4
+                        const int q = co / Cps, cc = co - q * Cps;
+                        dst = G.out + ((size_t)(b * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1)) * Cps + cc;
+                    }
+                    if (vec) *(f32x4*)dst = v;
+                    else
+                        for (int e = 0; e < 4; e++)
+                            if (co + e < G.Cout) dst[e] = v[e];
                 }
             }
         }
@@ -277,6 +293,7 @@ hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     else if (ks == 3 && nt == 2 && a.mw == 16) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 32, 1>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8>), grid, block, 0, s, a);
+    else if (ks == 3 && nt == 1 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8, false, 32, 1>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8>), grid, block, 0, s, a);
     else if (ks == 1 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 16>), grid, block, 0, s, a);
     else if (ks == 1 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 16>), grid, block, 0, s, a);

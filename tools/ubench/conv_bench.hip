@@ -27,6 +27,10 @@ __global__ void fill_rand(float* p, size_t n, float scale) {
         p[i] = ((int)(x & 0xffff) - 32768) * (scale / 32768.f);
     }
 }
+__global__ void relu_inplace(float* p, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = p[i] > 0.f ? p[i] : 0.f;
+}
 __global__ void fill_rand8(uint8_t* p, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; p[i] = (uint8_t)x; }
@@ -43,6 +47,12 @@ int main(int argc, char** argv) {
         {"conv3b pool", 120, 160, 128, 128, CONV_POOL2, 0, 32, 2, 1},
         {"conv4a plain nt1", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 1, 2},
         {"conv4a plain mw16", 60, 80, 128, 128, CONV_PLAIN, 0, 16, 2, 1},
+        {"conv4a plain nt1 nbuf1", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 1, 1},
+        {"conv4a plain mw32 nt2", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 2, 1},
+        {"h1 ps2-like plain", 120, 160, 64, 64, CONV_PLAIN, 0, 32, 2, 1},
+        {"h1 plain nt1 nbuf1", 120, 160, 64, 64, CONV_PLAIN, 0, 32, 1, 1},
+        {"h2 16->16 nt1 nbuf1", 240, 320, 16, 32, CONV_PLAIN, 0, 32, 1, 1},
+        {"h2 16->16 nt1 nbuf2", 240, 320, 16, 32, CONV_PLAIN, 0, 32, 1, 2},
         {"heads 768 mw16", 60, 80, 128, 768, CONV_PLAIN, 0, 16, 2, 1},
     };
     size_t maxin = (size_t)B * 480 * 640 * 64;
@@ -50,9 +60,11 @@ int main(int argc, char** argv) {
     hipMalloc(&din, maxin * 4 / 4); hipMalloc(&dout, maxin * 4); hipMalloc(&dw, 16 << 20); hipMalloc(&dbias, 4096);
     hipMalloc(&dimg, (size_t)B * 480 * 640);
     hipMemset(din, 0, maxin); hipMemset(dw, 0, 16 << 20); hipMemset(dbias, 0, 4096); hipMemset(dimg, 7, (size_t)B * 480 * 640);
-    const bool rnd = argc > 1 && atoi(argv[1]) == 1;
+    const int rmode = argc > 1 ? atoi(argv[1]) : 0;
+    const bool rnd = rmode != 0;
     if (rnd) {
-        fill_rand<<<4096, 256>>>(din, maxin / 4, 1.f);
+        fill_rand<<<4096, 256>>>(din, maxin / 4, rmode == 2 ? 1e-3f : rmode == 3 ? 1e-38f : 1.f);
+        if (rmode >= 2) relu_inplace<<<4096, 256>>>(din, maxin / 4);
         fill_rand<<<4096, 256>>>(dw, (16 << 20) / 4, 0.05f);
         fill_rand8<<<4096, 256>>>(dimg, (size_t)B * 480 * 640);
         hipDeviceSynchronize();
