@@ -151,28 +151,41 @@ def main():
     run(0, args.warmup + 1)  # +1: the very first batch has no previous frame to match
     for key in stats:
         stats[key] = 0
-    ctx.profile(True)
+    # Timed region: device events only around the dominant kernel (two per step), so that the measurement
+    # does not perturb the throughput it reports.
+    ctx.profile(2)
     barrier()
     t0 = time.perf_counter()
     run(args.warmup + 1, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
+    fl = ctx.last_profile_flops                # algorithmic FLOPs the library enqueued per kernel class
     ctx.profile(False)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    timed = dict(stats)                        # what the timed region saw
+    # Second, untimed pass with events around every kernel class: the per-class breakdown.
+    nb = min(args.steps, 12)
+    ctx.profile(1)
+    barrier()
+    run(args.warmup + 1 + args.steps, nb)
+    barrier()
+    prof_all = ctx.profile_read()
+    fl_all = ctx.last_profile_flops
+    ctx.profile(False)
 
     if rank == 0:
-        fl = ctx.last_profile_flops            # algorithmic FLOPs the library enqueued per kernel class
-        dom_ms, dom_launches = prof["conv3x3"]
-        flops_per_launch = fl["conv3x3"] / max(dom_launches, 1)
+        dom_ms, dom_launches = prof["conv1a"]
+        flops_per_launch = fl["conv1a"] / max(dom_launches, 1)
         avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
         achieved = flops_per_launch / avg_launch_s / 1e12 if dom_launches else 0.0
-        f_ms, f_launches = prof["conv1a"]
-        fused_tf = fl["conv1a"] / (f_ms * 1e-3) / 1e12 if f_launches else None
-        all_conv_tf = (fl["conv3x3"] + fl["conv1a"] + fl["conv_other"]) / ((dom_ms + f_ms + prof["conv_other"][0]) * 1e-3) / 1e12
+        o_ms, o_launches = prof_all["conv3x3"]
+        other_tf = fl_all["conv3x3"] / (o_ms * 1e-3) / 1e12 if o_launches else None
+        all_conv_tf = (fl_all["conv3x3"] + fl_all["conv1a"] + fl_all["conv_other"]) / \
+            ((o_ms + prof_all["conv1a"][0] + prof_all["conv_other"][0]) * 1e-3) / 1e12
         frames_total = B * args.steps * world
         out = {
             "metric": "front-end frames/sec (extract+describe+match) @640x480",
@@ -184,19 +197,22 @@ def main():
                                    f"full extract (CNN fp32 MFMA + NMS + line graph + descriptors, JUNCTION_MAX_NUM={args.max_num}) "
                                    f"+ all-pairs SearchForInitialization match vs previous frame; input resident in HBM",
                        "batch_per_gpu": B, "parallelism": f"stream-sharded x{world}, RCCL all-reduce(MIN) barrier per step",
-                       "avg_keypoints": round(stats["kp"] / (B * args.steps), 1),
-                       "avg_edges": round(stats["edges"] / (B * args.steps), 1),
-                       "avg_matches": round(stats["matches"] / (B * args.steps), 1)},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<3,2,8,false,*> (3x3 convolutions with 64-cout blocks after conv1b)",
+                       "avg_keypoints": round(timed["kp"] / (B * args.steps), 1),
+                       "avg_edges": round(timed["edges"] / (B * args.steps), 1),
+                       "avg_matches": round(timed["matches"] / (B * args.steps), 1)},
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv_mfma_kernel<3,2,8,true,32,1>: conv1a (1->64, on the fly) + conv1b (64->64, 3x3) + ReLU + "
+                                   "2x2 max-pool at full resolution; 40 % of the front-end's FLOPs, the longest launch of a step",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(dom_launches),
                          "flops_per_launch": flops_per_launch, "traffic": None,
-                         "conv1ab_fused": {"kernel": "conv_mfma_kernel<3,2,8,true> (conv1a+conv1b+pool)",
-                                           "achieved": round(fused_tf, 2) if fused_tf else None,
-                                           "avg_launch_ms": round(f_ms / max(f_launches, 1), 4)},
+                         "other_3x3_convolutions": {"kernel": "conv_mfma_kernel<3,2,8,false,*,1> (six launches per step)",
+                                                    "achieved": round(other_tf, 2) if other_tf else None,
+                                                    "ms_per_step": round(o_ms / nb, 4)},
                          "all_convolutions_achieved": round(all_conv_tf, 2)},
-            "device_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+            "device_ms_per_step": {k: round(v[0] / nb, 4) for k, v in prof_all.items()},
+            "device_ms_note": f"from a second pass of {nb} steps with events around every kernel class (not the timed region)",
         }
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):

@@ -212,6 +212,8 @@ void* ppg_stream(ppg_ctx* ctx);
 
 /* Device-time accounting with HIP events recorded on that stream around every launch (no counterpart in
  * the reference, which has no timers).  ppg_profile(ctx, 1) resets and enables, (ctx, 0) disables;
+ * (ctx, 2) resets and times only PPG_PROF_CONV1A on the device (two events per batch instead of two per
+ * kernel, which perturbs a throughput measurement far less) plus the host-side classes;
  * ppg_profile_read returns accumulated milliseconds and the number of timed launches per class. */
 #define PPG_PROF_CONV3X3 0     /* conv_mfma_kernel<3,2,8,false>: the 3x3 convolutions with >= 64 couts after conv1b */
 #define PPG_PROF_CONV_OTHER 1  /* the 1x1 convolutions and the 16-cout 3x3 one */

@@ -280,7 +280,7 @@ class Context:
         return cnts, m12
 
     def profile(self, enable=True):
-        self._chk(self.L.ppg_profile(C.c_void_p(self.h), 1 if enable else 0))
+        self._chk(self.L.ppg_profile(C.c_void_p(self.h), 2 if enable == 2 else (1 if enable else 0)))
 
     def profile_read(self):
         ms = (C.c_double * 10)()

@@ -141,7 +141,7 @@ struct ppg_ctx {
     int32_t* d_match = nullptr;
     int* d_mcounts = nullptr;
     // optional per-kernel-class timing with HIP events on the context's stream
-    bool prof = false;
+    int prof = 0;  // 0 off, 1 every class, 2 device events for the fused first convolution only (+ host timers)
     std::vector<hipEvent_t> ev_all, ev_free;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pairs;
     double prof_ms[PPG_PROF_N] = {};
@@ -200,7 +200,7 @@ struct ProfScope {
     hipEvent_t e0 = nullptr;
     hipStream_t st;
     ProfScope(ppg_ctx* ctx, int k, hipStream_t s) : c(ctx), cls(k), st(s) {
-        if (c->prof && (e0 = prof_event(c))) (void)hipEventRecord(e0, st);
+        if ((c->prof == 1 || (c->prof == 2 && cls == PPG_PROF_CONV1A)) && (e0 = prof_event(c))) (void)hipEventRecord(e0, st);
     }
     ~ProfScope() {
         if (!e0) return;
@@ -1372,7 +1372,7 @@ int ppg_match_prev_batch(ppg_ctx* c, int n, float nnratio, int32_t* m12, int* n_
 
 int ppg_profile(ppg_ctx* c, int enable) {
     if (!c) return PPG_EINVAL;
-    c->prof = enable != 0;
+    c->prof = enable == 2 ? 2 : (enable != 0);
     for (int k = 0; k < PPG_PROF_N; k++) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_flops[k] = 0; }
     return PPG_OK;
 }
