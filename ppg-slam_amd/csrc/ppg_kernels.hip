@@ -85,14 +85,20 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
 #pragma unroll
     for (int k = 0; k < IN_PER_T; k++) {
         const int item = tid + 256 * k;
-        const int pix = item / QPP, q = item % QPP;
+        // slot -> (pixel, channel quad).  FUSE1A (QPP = 2): the four lanes of an MFMA 4x4 block share a quad
+        // and own four different pixels.
+        const int pix = FUSE1A ? 128 * k + (tid >> 3) * 4 + (tid & 3) : item / QPP;
+        const int q = FUSE1A ? (tid >> 2) & 1 : item % QPP;
         const int py = pix / IW, px = pix % IW;
         const int gy = y0 + py - PAD, gx = x0 + px - PAD;
         lofs[k] = pix * PSTR + q * 4;
         gofs[k] = NOWHERE;
-        if (item < IN_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+        if (pix < IN_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
             gofs[k] = FUSE1A ? (unsigned)(py * PW + px) : (unsigned)(((gy * a.W + gx) * a.Cin + q * 4) * 4);
     }
+    int pofs[IN_PER_T];  // FUSE1A: patch offset of the slot's pixel, 0 for the slots that produce zeros
+#pragma unroll
+    for (int k = 0; k < IN_PER_T; k++) pofs[k] = FUSE1A && gofs[k] != NOWHERE ? (int)gofs[k] : 0;
     // image b of the input and the packed weights of cout block nb, as buffers
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.in + (FUSE1A ? 0 : (size_t)b * a.H * a.W * a.Cin)), 0, FUSE1A ? 0 : a.H * a.W * a.Cin * 4, 0x00020000);
@@ -124,30 +130,28 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
             for (int k = 0; k < IN_PER_T; k++)
                 vin[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, gofs[k], c * KC * 4, 0));
         } else {
-            // conv1a + ReLU for 4 channels of one pixel: bias, then the nine taps in (ky, kx) order, fmaf
-            // (backbone.py:28) — the same chain as conv1a_kernel, two channels per packed FMA.  All slots of
-            // a thread serve the same 4 channels.  Pixels outside the image are this layer's zero padding.
-            const int ch = c * KC + (tid % QPP) * 4;
+            // conv1a + ReLU for 4 channels of one pixel: bias, then the nine taps in (ky, kx) order, each one
+            // fused multiply-add (backbone.py:28) — the same chain as conv1a_kernel, evaluated by
+            // v_mfma_f32_4x4x1 (16 independent 4x4 outer products per instruction: rows = the quad's four
+            // channels, columns = the block's four pixels), which costs an eighth of the VALU slots.
+            // Slots that produce zeros (padding of this layer, slots past the tile) run on patch offset 0.
+            const int ch = c * KC + ((tid >> 2) & 1) * 4;
             const f32x4 bias = *(const f32x4*)(b1s + ch);
-            f32x4 w9[9];
+            f32x4 o[IN_PER_T];
 #pragma unroll
-            for (int t = 0; t < 9; t++) w9[t] = *(const f32x4*)(w1s + t * 64 + ch);
+            for (int k = 0; k < IN_PER_T; k++) o[k] = bias;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const float wa = w1s[t * 64 + ch + (tid & 3)];
+#pragma unroll
+                for (int k = 0; k < IN_PER_T; k++)
+                    o[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa, patch[pofs[k] + (t / 3) * PW + (t % 3)], o[k], 0, 0, 0);
+            }
 #pragma unroll
             for (int k = 0; k < IN_PER_T; k++) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                vin[k] = z;
-                if (gofs[k] != NOWHERE) {
-                    const float* pp = patch + gofs[k];
-                    f32x2 lo = {bias[0], bias[1]}, hi = {bias[2], bias[3]};
+                const bool in = gofs[k] != NOWHERE;
 #pragma unroll
-                    for (int t = 0; t < 9; t++) {
-                        const float v = pp[(t / 3) * PW + (t % 3)];
-                        const f32x2 vv = {v, v};
-                        lo = __builtin_elementwise_fma(vv, (f32x2){w9[t][0], w9[t][1]}, lo);
-                        hi = __builtin_elementwise_fma(vv, (f32x2){w9[t][2], w9[t][3]}, hi);
-                    }
-                    vin[k] = (f32x4){fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f), fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
-                }
+                for (int e = 0; e < 4; e++) vin[k][e] = in ? fmaxf(o[k][e], 0.f) : 0.f;
             }
         }
     };
