@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="independent camera streams per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="independent camera streams per GPU per step")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--max-num", type=int, default=1024, help="JUNCTION_MAX_NUM (1024-keypoint match config)")
