@@ -12,6 +12,7 @@ namespace ppg {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load from a 4-byte aligned address
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // =====================================================================================
@@ -480,6 +481,12 @@ __global__ __launch_bounds__(256) void nms_suppress_kernel(NmsArgs a) {
         rowany[ly][lx] = any;
     }
     __syncthreads();
+    // the tile's kept and residual pixels are gathered in LDS and appended to the frame's lists with one
+    // global atomic each (the lists are unordered; a per-pixel atomic on the frame counter serialises)
+    __shared__ uint32_t l_kept[NT_TILE * NT_TILE], l_res[NT_TILE * NT_TILE];
+    __shared__ int n_kept, n_res, g_kept, g_res;
+    if (threadIdx.x == 0) { n_kept = 0; n_res = 0; }
+    __syncthreads();
     int* cnt = a.counters + b * 8;
     for (int i = threadIdx.x; i < NT_TILE * NT_TILE; i += 256) {
         const int ly = i / NT_TILE, lx = i % NT_TILE;
@@ -488,8 +495,7 @@ __global__ __launch_bounds__(256) void nms_suppress_kernel(NmsArgs a) {
         const uint8_t s0 = sh[ly + NR][lx + NR];
         const uint32_t idx = (uint32_t)(gy * a.W + gx);
         if (s0 == 2) {
-            const int k = atomicAdd(&cnt[1], 1);
-            if (k < a.kept_cap) a.kept[(size_t)b * a.kept_cap + k] = idx;
+            l_kept[atomicAdd(&n_kept, 1)] = idx;
         } else if (s0 == 1) {
             uint8_t sup = 0;
 #pragma unroll
@@ -498,11 +504,20 @@ __global__ __launch_bounds__(256) void nms_suppress_kernel(NmsArgs a) {
                 // only this thread writes this pixel; neighbours test for == 2 only, which never changes here
                 st[idx] = 3;
             } else {
-                const int k = atomicAdd(&cnt[0], 1);
-                if (k < a.resid_cap) a.resid[(size_t)b * a.resid_cap + k] = idx;
+                l_res[atomicAdd(&n_res, 1)] = idx;
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g_kept = n_kept ? atomicAdd(&cnt[1], n_kept) : 0;
+        g_res = n_res ? atomicAdd(&cnt[0], n_res) : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_kept; i += 256)
+        if (g_kept + i < a.kept_cap) a.kept[(size_t)b * a.kept_cap + g_kept + i] = l_kept[i];
+    for (int i = threadIdx.x; i < n_res; i += 256)
+        if (g_res + i < a.resid_cap) a.resid[(size_t)b * a.resid_cap + g_res + i] = l_res[i];
 }
 
 __global__ __launch_bounds__(1024) void nms_resolve_kernel(NmsArgs a) {
@@ -715,6 +730,7 @@ __global__ __launch_bounds__(256) void refine_kernel(HeatArgs a) {
     __shared__ int s_n;
     __shared__ float s_ave;
     __shared__ int s_action;  // 0 leave, 1 zero, 2 rescale
+    __shared__ int s_big;     // some value exceeds 1 (cannot happen for softmax output)
     const int S = a.refine_sz;
     const int gxn = a.W / S, gyn = a.H / S;
     const int tj = blockIdx.x % gxn, ti = (blockIdx.x / gxn) % gyn, b = blockIdx.x / (gxn * gyn);
@@ -725,6 +741,8 @@ __global__ __launch_bounds__(256) void refine_kernel(HeatArgs a) {
     float* dst = a.refined + (size_t)b * a.H * a.W;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
+    if (tid == 0) s_big = 0;
+    __syncthreads();
     // ordered compaction, 256 pixels per pass
     int base = 0;
     for (int p0 = 0; p0 < area; p0 += 256) {
@@ -734,6 +752,7 @@ __global__ __launch_bounds__(256) void refine_kernel(HeatArgs a) {
         if (p < area) {
             v = src[(size_t)(h0 + p / segW) * a.W + w0 + p % segW];
             ok = v > a.valid_thresh;
+            if (v > 1.0f) s_big = 1;
         }
         const unsigned long long m = __ballot(ok);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
@@ -755,7 +774,61 @@ __global__ __launch_bounds__(256) void refine_kernel(HeatArgs a) {
     }
     __syncthreads();
     const int action = s_action, valCount = s_n;
-    if (action == 2) {
+    // The mean of the valCount largest values is accumulated in double by the reference.  Every value lies in
+    // (valid_thresh, 1] (checked: s_big); with valid_thresh >= 2^-20 all of them are multiples of 2^-43, so any sum of up to
+    // 1024 of them is exact in double and the order of the additions cannot change the result.  Then it is
+    // enough to find the valCount-th largest value T (radix select on the bit patterns, 8 bits per pass):
+    // sum = sum of the values above T + (valCount - their number) * T.
+    if (action == 2 && a.valid_thresh >= 0x1p-20f && !s_big) {
+        __shared__ int hist[256];
+        __shared__ int wtot[4];
+        __shared__ int s_bin, s_k;
+        __shared__ double wsum[4];
+        __shared__ int wcnt2[4];
+        unsigned prefix = 0, mask = 0;
+        int kk = valCount;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int k = tid; k < n; k += 256) {
+                const unsigned u = __float_as_uint(vals[k]);
+                if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            const int c = hist[255 - tid];  // bins in descending order
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (lane == 63) wtot[wave] = inc;
+            __syncthreads();
+            for (int w = 0; w < wave; w++) inc += wtot[w];
+            const int exc = inc - c;
+            if (exc < kk && kk <= inc) { s_bin = 255 - tid; s_k = kk - exc; }
+            __syncthreads();
+            prefix |= (unsigned)s_bin << shift;
+            mask |= 255u << shift;
+            kk = s_k;
+        }
+        double part = 0.0;
+        int above = 0;
+        for (int k = tid; k < n; k += 256) {
+            const float v = vals[k];
+            if (__float_as_uint(v) > prefix) { part += (double)v; above++; }
+        }
+        part = wave_sum_d(part);
+        for (int o = 32; o > 0; o >>= 1) above += __shfl_xor(above, o);
+        if (lane == 0) { wsum[wave] = part; wcnt2[wave] = above; }
+        __syncthreads();
+        if (tid == 0) {
+            const double acc = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) +
+                               (double)(valCount - (wcnt2[0] + wcnt2[1] + wcnt2[2] + wcnt2[3])) * (double)__uint_as_float(prefix);
+            s_ave = (float)(acc / (double)(float)valCount);
+        }
+        __syncthreads();
+    } else if (action == 2) {
         for (int k = tid; k < n; k += 256) {
             const float v = vals[k];
             int rank = 0;
@@ -908,11 +981,21 @@ __global__ __launch_bounds__(256) void line_score_kernel(LineArgs a) {
             const float sx = psx * step * (float)t + pex * step * (float)(segNum - t);
             const float sy = psy * step * (float)t + pey * step * (float)(segNum - t);
             const int px = (int)((double)sx + 0.5), py = (int)((double)sy + 0.5);
-            if (heat_at(heat, a.W, py, px) > a.heat_thresh) inl++;
-            // bilinearInterpolation, PPGExtractor.cpp:580-589
+            // bilinearInterpolation, PPGExtractor.cpp:580-589.  Its four taps are two 8-byte loads, and the
+            // rounded sample position of the inlier test is one of them (sx, sy >= 0 for in-image end points).
             const int x1 = (int)sx, x2 = x1 + 1, y1 = (int)sy, y2 = y1 + 1;
-            const float d1 = ((float)x2 - sx) * heat_at(heat, a.W, y1, x1) + (sx - (float)x1) * heat_at(heat, a.W, y1, x2);
-            const float d2 = ((float)x2 - sx) * heat_at(heat, a.W, y2, x1) + (sx - (float)x1) * heat_at(heat, a.W, y2, x2);
+            const f32x2u r1 = *(const f32x2u*)(heat + (size_t)y1 * a.W + x1);
+            const f32x2u r2 = *(const f32x2u*)(heat + (size_t)y2 * a.W + x1);
+            float hp;
+            if ((px == x1 || px == x2) && (py == y1 || py == y2)) {
+                const f32x2u r = py == y1 ? r1 : r2;
+                hp = px == x1 ? r[0] : r[1];
+            } else {
+                hp = heat_at(heat, a.W, py, px);
+            }
+            if (hp > a.heat_thresh) inl++;
+            const float d1 = ((float)x2 - sx) * r1[0] + (sx - (float)x1) * r1[1];
+            const float d2 = ((float)x2 - sx) * r2[0] + (sx - (float)x1) * r2[1];
             sum += ((float)y2 - sy) * d1 + (sy - (float)y1) * d2;
         }
         float* o = a.cand_sc + ((size_t)b * a.cand_cap + k) * 2;
