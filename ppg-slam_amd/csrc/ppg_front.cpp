@@ -133,7 +133,6 @@ struct ppg_ctx {
     int host_threads = 1;
     bool skip_score = false, skip_heat = false, skip_refine = false;
     bool unfused_conv1a = false;
-    int conv_nbuf = 1;
     int last_n = 0;
     // previous extract call's descriptors / counts stay resident for frame-to-frame matching
     float* desc_prev = nullptr;
@@ -461,7 +460,6 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
     a.mw = fused_img ? 32 : pick_tile(dc, H, W, mode);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw); a.nblk = dc.nblk;
     a.ngroups = 1;
-    a.nbuf = c->conv_nbuf;
     a.g[0] = conv_group(dc, out, mode, relu, 0);
     const int cls = fused_img ? PPG_PROF_CONV1A : (dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER);
     if (c->prof) c->prof_flops[cls] += 2.0 * n * H * W * (double)dc.cin * dc.cout * dc.ks * dc.ks + (fused_img ? 2.0 * n * H * W * 9.0 * 64 : 0.0);
@@ -480,7 +478,6 @@ int run_heads(ppg_ctx* c, int n, int H, int W) {
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
     a.nblk = c->pa.nblk + c->da.nblk + c->h0.nblk;
     a.ngroups = 3;
-    a.nbuf = c->conv_nbuf;
     a.g[0] = conv_group(c->pa, c->pa_o, ppg::CONV_PLAIN, 1, 0);
     a.g[1] = conv_group(c->da, c->da_o, ppg::CONV_PLAIN, 1, c->pa.nblk);
     a.g[2] = conv_group(c->h0, c->hs0, ppg::CONV_PS2, 1, c->pa.nblk + c->da.nblk);
@@ -614,8 +611,6 @@ static int create_impl(ppg_ctx* c) {
     {
         const char* u = getenv("PPG_UNFUSED_CONV1A");
         c->unfused_conv1a = u && atoi(u) != 0;
-        const char* nbf = getenv("PPG_CONV_NBUF");
-        if (nbf && atoi(nbf) == 2) c->conv_nbuf = 2;
         const char* nl = getenv("PPG_CNN_LANES");
         if (nl && atoi(nl) == 2) c->nlanes = 2;
         const char* e = getenv("PPG_HOST_THREADS");

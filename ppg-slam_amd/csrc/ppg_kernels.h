@@ -30,7 +30,6 @@ struct ConvArgs {
     int B, H, W, Cin;
     int tiles_x, tiles_y, nblk;  // nblk = cout blocks of all groups together
     int mw = 32;         // tile shape: 32 -> 8 x 32 pixels, 16 -> 16 x 16 pixels (3x3, 64-cout blocks only)
-    int nbuf = 2;        // LDS buffers per work-group: 2 -> two work-groups per CU, 1 -> three
     int ngroups = 1;
     ConvGroup g[3];
 };

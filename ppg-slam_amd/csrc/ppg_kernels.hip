@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //  net/EdgeHeatmap.pt .../heatmap_decoder.py:19-22).
 //
 // Work-group = 4 waves, output tile 8 rows x 32 columns x NB couts (NB = 32*NT).
-// Wave w owns rows 2w, 2w+1 (two 32-pixel M tiles) x NT 32-cout N tiles.
+// Wave w owns rows 2w, 2w+1 (two 32-pixel tiles) x NT 32-cout tiles.
 //   A operand (lane l): cout = l&31,                 cin = 4*(l>>5)+s for the s-th MFMA of a group
 //   B operand (lane l): pixel x = l&31 of the row,   same cin
 //   D: lane holds pixel l&31; register r holds cout (r&3) + 8*(r>>2) + 4*(l>>5)
@@ -33,14 +33,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // max-pool is: vertical = the two pixel tiles, horizontal = the neighbouring lane (one DPP move).
 // Input is streamed through LDS in chunks of KC input channels (pixel stride KC+4 floats keeps the
 // 16-byte fragment reads of a 16-lane group on distinct banks); weights arrive pre-packed in
-// exactly the LDS image order.  Two LDS buffers: the next chunk is fetched into registers before the
-// MFMAs of the current one and written to the other buffer after them, one barrier per chunk.
+// exactly the LDS image order.  One LDS buffer (39 KiB, so three work-groups share a CU): the next chunk is
+// fetched into registers by branch-free buffer loads before the MFMAs of the current one (padding pixels
+// and slots past the tile carry an offset outside the buffer and load zeros), and written to LDS between
+// two barriers after them.  Straight-line staging matters: with per-load branches the compiler guards the
+// register reuse with vmcnt waits that stall every wave on its own prefetch.
 // =====================================================================================
 // Two tile shapes (MW = width of one 32-pixel M tile): MW = 32 -> 8 rows x 32 columns per work-group (an M
 // tile is one row segment), MW = 16 -> 16 x 16 (an M tile is 2 rows x 16 columns), which wastes less of
 // feature maps whose width is a multiple of 16 but not of 32 (e.g. 80 columns at 640/8).
-template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32, int NBUF = 2>
-__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
+template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32>
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     constexpr int TW = MW, TH = 256 / MW;
     constexpr int PAD = KS / 2;
     constexpr int IH = TH + KS - 1, IW = TW + KS - 1, IN_PIX = IH * IW;
@@ -58,13 +61,13 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
     // of the tile land in padding
     constexpr int IN_FLOATS_P = (IN_PER_T * 256 / QPP) * PSTR;
     constexpr int W_FLOATS_P = W_PER_T * 256 * 4;
-    constexpr int BUF = IN_FLOATS_P + W_FLOATS_P;
+    constexpr int BUF = IN_FLOATS_P + W_FLOATS_P;  // one staging buffer: three work-groups per CU
     // FUSE1A: the input of this layer is conv1a(image) and is computed on the fly from the u8 patch of
     // the tile (two halo rings) instead of being read from memory: patch as floats + conv1a weights.
     constexpr int PH = IH + 2, PW = IW + 2;
     constexpr int FUSE_FLOATS = FUSE1A ? (PH * PW + 9 * 64 + 64) : 0;
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF + FUSE_FLOATS];
-    float* patch = smem + NBUF * BUF;        // [PH][PW]
+    __shared__ __attribute__((aligned(16))) float smem[BUF + FUSE_FLOATS];
+    float* patch = smem + BUF;        // [PH][PW]
     float* w1s = patch + PH * PW;            // [9][64]
     float* b1s = w1s + 9 * 64;               // [64]
 
@@ -156,11 +159,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
             }
         }
     };
-    auto stash = [&](int buf) {
-        float* ins = smem + buf * BUF;
-        float* ws = ins + IN_FLOATS_P;
+    auto stash = [&]() {
+        float* ws = smem + IN_FLOATS_P;
 #pragma unroll
-        for (int k = 0; k < IN_PER_T; k++) *(f32x4*)(ins + lofs[k]) = vin[k];
+        for (int k = 0; k < IN_PER_T; k++) *(f32x4*)(smem + lofs[k]) = vin[k];
 #pragma unroll
         for (int k = 0; k < W_PER_T; k++) *(f32x4*)(ws + (tid + 256 * k) * 4) = vw[k];
     };
@@ -174,13 +176,12 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
     fetch(0);
-    stash(0);
+    stash();
     __syncthreads();
+    const float* ins = smem;
+    const float* ws = smem + IN_FLOATS_P;
     for (int c = 0; c < nchunks; c++) {
-        const int buf = NBUF == 2 ? (c & 1) : 0;
         if (c + 1 < nchunks) fetch(c + 1);
-        const float* ins = smem + buf * BUF;
-        const float* ws = ins + IN_FLOATS_P;
 #pragma unroll
         for (int g = 0; g < KC / 8; g++) {
 #pragma unroll
@@ -202,16 +203,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void conv_mfma_kernel(ConvA
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[n][s], av[m][s], acc[m][n], 0, 0, 0);
             }
         }
-        if (NBUF == 2) {
-            if (c + 1 < nchunks) stash(buf ^ 1);
-            __syncthreads();
-        } else {
-            // one LDS buffer (three work-groups per CU instead of two): everybody must be done reading
-            // the chunk before it is overwritten
-            __syncthreads();
-            if (c + 1 < nchunks) stash(0);
-            __syncthreads();
-        }
+        // everybody must be done reading the chunk before it is overwritten
+        __syncthreads();
+        if (c + 1 < nchunks) stash();
+        __syncthreads();
     }
 
     // ---- epilogue: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store ----
@@ -292,13 +287,10 @@ hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     if (a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
     // one image of the input is addressed as a buffer with 32-bit byte offsets
     if ((long)a.H * a.W * a.Cin * 4 > 0x7fffffffL) return hipErrorInvalidValue;
-    if (ks == 3 && nt == 2 && a.img && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true, 32, 1>), grid, block, 0, s, a);
-    else if (ks == 3 && nt == 2 && a.img) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true>), grid, block, 0, s, a);
-    else if (ks == 3 && nt == 2 && a.mw == 16 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16, 1>), grid, block, 0, s, a);
+    if (a.img && (ks != 3 || nt != 2 || a.Cin != 64 || a.mw != 32)) return hipErrorInvalidValue;
+    if (ks == 3 && nt == 2 && a.img) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2 && a.mw == 16) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16>), grid, block, 0, s, a);
-    else if (ks == 3 && nt == 2 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 32, 1>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8>), grid, block, 0, s, a);
-    else if (ks == 3 && nt == 1 && a.nbuf == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8, false, 32, 1>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8>), grid, block, 0, s, a);
     else if (ks == 1 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 16>), grid, block, 0, s, a);
     else if (ks == 1 && nt == 1) hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 16>), grid, block, 0, s, a);

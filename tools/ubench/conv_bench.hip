@@ -35,7 +35,7 @@ __global__ void fill_rand8(uint8_t* p, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; p[i] = (uint8_t)x; }
 }
-struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, nbuf; };
+struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, nbuf, ks = 3; };
 int main(int argc, char** argv) {
     const int B = 16;
     std::vector<L> ls = {
@@ -54,6 +54,10 @@ int main(int argc, char** argv) {
         {"h2 16->16 nt1 nbuf1", 240, 320, 16, 32, CONV_PLAIN, 0, 32, 1, 1},
         {"h2 16->16 nt1 nbuf2", 240, 320, 16, 32, CONV_PLAIN, 0, 32, 1, 2},
         {"heads 768 mw16", 60, 80, 128, 768, CONV_PLAIN, 0, 16, 2, 1},
+        {"db 1x1 256->256 nbuf2", 60, 80, 256, 256, CONV_PLAIN, 0, 32, 2, 2, 1},
+        {"db 1x1 256->256 nbuf1", 60, 80, 256, 256, CONV_PLAIN, 0, 32, 2, 1, 1},
+        {"pb 1x1 256->96 nbuf2", 60, 80, 256, 96, CONV_PLAIN, 0, 32, 1, 2, 1},
+        {"pb 1x1 256->96 nbuf1", 60, 80, 256, 96, CONV_PLAIN, 0, 32, 1, 1, 1},
     };
     size_t maxin = (size_t)B * 480 * 640 * 64;
     float *din, *dout, *dw, *dbias; uint8_t* dimg;
@@ -78,18 +82,18 @@ int main(int argc, char** argv) {
         if (l.fused) { a.img = dimg; a.w1a = dw; a.b1a = dbias; }
         const int tw = l.mw, th = 256 / l.mw;
         a.tiles_x = (l.W + tw - 1) / tw; a.tiles_y = (l.H + th - 1) / th; a.nblk = l.Cout / (32 * l.nt);
-        a.mw = l.mw; a.nbuf = l.nbuf; a.ngroups = 1;
+        a.mw = l.mw; a.ngroups = 1;
         a.g[0].out = dout; a.g[0].bias = dbias; a.g[0].nblk0 = 0; a.g[0].Cout = l.Cout; a.g[0].mode = l.mode; a.g[0].relu = 1;
-        for (int i = 0; i < 3; i++) launch_conv(a, 3, l.nt, 0);
+        for (int i = 0; i < 3; i++) launch_conv(a, l.ks, l.nt, 0);
         hipDeviceSynchronize();
         const int reps = 10;
-        float est; { hipEventRecord(e0); launch_conv(a, 3, l.nt, 0); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&est, e0, e1); }
+        float est; { hipEventRecord(e0); launch_conv(a, l.ks, l.nt, 0); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&est, e0, e1); }
         hipEventRecord(e0);
         clock_probe<<<1, 64, 0, s2>>>(dclk, (long long)(est * reps * 0.8 * 1e5));
-        for (int i = 0; i < reps; i++) if (launch_conv(a, 3, l.nt, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
+        for (int i = 0; i < reps; i++) if (launch_conv(a, l.ks, l.nt, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-        double fl = 2.0 * B * l.H * l.W * l.Cin * l.Cout * 9;
+        double fl = 2.0 * B * l.H * l.W * l.Cin * l.Cout * l.ks * l.ks;
         hipStreamSynchronize(s2);
         hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost);
 #ifdef TRACE
