@@ -122,7 +122,8 @@ def test_ragged_sizes_vs_oracle(pkg, orc, onet, synth):
 
 def test_full_size_postprocessing_exact_on_gpu_tensors(pkg, orc, synth):
     """BASELINE sizes: every integer output equals the oracle's when both start from the GPU's CNN tensors."""
-    for (H, W, seed, kind, maxnum) in ((480, 640, 31, "sparse", 500), (480, 640, 32, "dense", 1024), (512, 512, 33, "dense", 1024)):
+    for (H, W, seed, kind, maxnum) in ((480, 640, 31, "sparse", 500), (480, 640, 32, "dense", 1024), (512, 512, 33, "dense", 1024),
+                                       (1024, 1024, 34, "sparse", 1024)):
         ctx = get_ctx(pkg, W, H, maxnum)
         img = synth.make_frame(H, W, seed, 0, kind)
         r = ctx.extract(img)
@@ -152,6 +153,20 @@ def test_batch_equals_single(pkg, synth):
     again = ctx.extract_batch(imgs[:3])
     for r, s in zip(again, singles[:3]):
         assert np.array_equal(r["xy"], s["xy"]) and np.array_equal(r["desc"], s["desc"])
+
+
+def test_bench_batch_equals_single_vga(pkg, synth):
+    """The bench configuration (32 VGA streams per step, 1024 key points): every frame of the batch equals the
+    same frame extracted alone, bit for bit (batching must not change any result)."""
+    H, W, B = 480, 640, 32
+    imgs = [synth.make_frame(H, W, 700 + k, k % 5, "dense" if k % 3 else "sparse") for k in range(B)]
+    ctx = get_ctx(pkg, W, H, 1024, batch=B)
+    rs = ctx.extract_batch(imgs)
+    one = get_ctx(pkg, W, H, 1024)
+    for k in (0, 7, 16, 31):
+        s = one.extract(imgs[k])
+        for key in ("xy", "score", "un", "out", "desc", "edge_idx", "edge_score", "conn_idx", "coline_pairs"):
+            assert np.array_equal(rs[k][key], s[key], equal_nan=True), (k, key)
 
 
 def test_degenerate_frames(pkg):
