@@ -182,6 +182,41 @@ ppg_grid* ppg_grid_build(const ppg_config* cfg, const float* pos, int n);
 void ppg_grid_free(ppg_grid* g);
 int ppg_features_in_area(const ppg_grid* g, float x, float y, float r, int32_t* out, int cap);
 
+/* GeometricCamera::IsInImage (sensors/src/GeometricCamera.cpp:21-24) with the bounds the grid was built with. */
+int ppg_grid_is_in_image(const ppg_grid* g, float x, float y);
+
+/* The windowed projection matchers: Matcher::SearchByProjection(Frame&, const Frame&, th) (matching/src/Matcher.cpp:31-87),
+ * SearchByProjection(Frame&, vector<MapPoint*>&, th) (:89-189), SearchByProjection(KeyFrame*, Sim3f&, ...) (:479-568),
+ * Fuse(KeyFrame*, vector<MapPoint*>&, th) (:897-1036) and Fuse(KeyFrame*, Sim3f&, ...) (:1038-1135) share one inner
+ * loop: per projected map point, in order, the candidates of GetFeaturesInArea(uv, radius) in grid order, some slots
+ * skipped, first argmin of DescriptorDistance, an accept rule, and (for two of them) an accepted match blocks its
+ * slot for the rows after it.  The caller keeps the geometry gates (pose, depth, scale range, viewing angle) and
+ * the map side effects; this call evaluates the loop with every candidate distance computed on the GPU.
+ *   row_ok[i] == 0        the row is skipped (a gate failed before GetFeaturesInArea)
+ *   slot_blocked (in/out) slots never taken: F.mvpMapPoints[i2]->Observations() > 0 (:67-69, :154-156) or
+ *                         vpMatched[idx] != nullptr (:546); may be NULL
+ *   row_claims[i] != 0    an accepted match of row i sets slot_blocked[best] (pMP->Observations() > 0 for :80,
+ *                         always for :562); may be NULL (Fuse)
+ *   e2_max >= 0           candidates whose squared distance to uv exceeds it are skipped (:992-997: 5.99)
+ *   accept                best <= th, and when ratio > 0 also !(best > ratio * second) (:177-180)
+ * best_idx[i] = accepted slot or -1, best_dist[i] = its distance (1e6 when the row had no candidate). */
+typedef struct ppg_proj_args {
+    const ppg_grid* grid;
+    const float* desc2;
+    int n2;
+    const float* desc1;
+    int n1;
+    const float* uv;
+    const float* radius;
+    const uint8_t* row_ok;
+    const uint8_t* row_claims;
+    uint8_t* slot_blocked;
+    float th;
+    float ratio;
+    float e2_max;
+} ppg_proj_args;
+int ppg_match_projected(ppg_ctx* ctx, const ppg_proj_args* args, int32_t* best_idx, float* best_dist, int* n_matches);
+
 /* Matcher::ExtendMapMatches (matching/include/Matcher.h:54, Matcher.cpp:203-381) on flattened state.
  * Map points are numbered 0..m-1 in vpMapPoints order.  Per point: descriptor, mTrackProjX/Y,
  * mTrackViewCos, mbTrackInView, isBad(), Observations(), and getEdges() as CSR entries carrying the

@@ -178,6 +178,81 @@ def search_for_initialization(cfg, nnratio, desc1, desc2, pos2, prev_matched, wi
     return cnt, m12, prev
 
 
+class Pose(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+class MapPoints(C.Structure):
+    _fields_ = [("m", C.c_int), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_dist", C.c_void_p),
+                ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("bad", C.c_void_p), ("nobs", C.c_void_p)]
+
+
+def _mappoints(mp):
+    """mp: dict pos[m,3] normal[m,3] min_dist[m] max_dist[m] desc[m,256] bad[m] nobs[m]; returns (struct, keep-alive)."""
+    keep = {"pos": np.ascontiguousarray(mp["pos"], np.float32), "normal": np.ascontiguousarray(mp["normal"], np.float32),
+            "min_dist": np.ascontiguousarray(mp["min_dist"], np.float32), "max_dist": np.ascontiguousarray(mp["max_dist"], np.float32),
+            "desc": np.ascontiguousarray(mp["desc"], np.float32), "bad": np.ascontiguousarray(mp["bad"], np.uint8),
+            "nobs": np.ascontiguousarray(mp["nobs"], np.int32)}
+    st = MapPoints()
+    st.m = int(keep["bad"].shape[0])
+    for k, a in keep.items():
+        setattr(st, k, a.ctypes.data)
+    return st, keep
+
+
+def _pose(R, t):
+    p = Pose()
+    for k, v in enumerate(np.asarray(R, np.float32).reshape(9)):
+        p.R[k] = float(v)
+    for k, v in enumerate(np.asarray(t, np.float32).reshape(3)):
+        p.t[k] = float(v)
+    return p
+
+
+def search_by_projection_frames(cfg, R, t, mp, last_mp, last_outlier, cur_pos, cur_desc, cur_mp, th):
+    st, keep = _mappoints(mp)
+    pose = _pose(R, t)
+    last_mp = np.ascontiguousarray(last_mp, np.int32)
+    last_outlier = np.ascontiguousarray(last_outlier, np.uint8)
+    cur_pos = np.ascontiguousarray(cur_pos, np.float32)
+    cur_desc = np.ascontiguousarray(cur_desc, np.float32)
+    cur = np.array(cur_mp, dtype=np.int32, order="C", copy=True)
+    L = lib()
+    L.ppgo_search_by_projection_frames.restype = C.c_int
+    n = L.ppgo_search_by_projection_frames(C.byref(cfg), C.byref(pose), C.byref(st), int(last_mp.shape[0]), _p(last_mp),
+                                           _p(last_outlier), int(cur.shape[0]), _p(cur_pos), _p(cur_desc), _p(cur), C.c_float(th))
+    return n, cur
+
+
+def search_by_projection_sim3(cfg, R, t, mp, points, kf_pos, kf_desc, matched, th, ratio_hamming):
+    st, keep = _mappoints(mp)
+    pose = _pose(R, t)
+    points = np.ascontiguousarray(points, np.int32)
+    kf_pos = np.ascontiguousarray(kf_pos, np.float32)
+    kf_desc = np.ascontiguousarray(kf_desc, np.float32)
+    m = np.array(matched, dtype=np.int32, order="C", copy=True)
+    L = lib()
+    L.ppgo_search_by_projection_sim3.restype = C.c_int
+    n = L.ppgo_search_by_projection_sim3(C.byref(cfg), C.byref(pose), C.byref(st), int(points.shape[0]), _p(points),
+                                         int(m.shape[0]), _p(kf_pos), _p(kf_desc), _p(m), int(th), C.c_float(ratio_hamming))
+    return n, m
+
+
+def fuse_match(cfg, R, t, mp, points, in_kf, kf_pos, kf_desc, th, with_e2):
+    st, keep = _mappoints(mp)
+    pose = _pose(R, t)
+    points = np.ascontiguousarray(points, np.int32)
+    in_kf = np.ascontiguousarray(in_kf, np.uint8)
+    kf_pos = np.ascontiguousarray(kf_pos, np.float32)
+    kf_desc = np.ascontiguousarray(kf_desc, np.float32)
+    best = np.full(points.shape[0], -1, np.int32)
+    L = lib()
+    L.ppgo_fuse_match.restype = C.c_int
+    n = L.ppgo_fuse_match(C.byref(cfg), C.byref(pose), C.byref(st), int(points.shape[0]), _p(points), _p(in_kf),
+                          int(kf_pos.shape[0]), _p(kf_pos), _p(kf_desc), C.c_float(th), int(bool(with_e2)), _p(best))
+    return n, best
+
+
 def extend_map_matches(cfg, nnratio, th, g, desc, pos_un, edge_idx, conn_off, conn_idx, tracked, frame_mp, frame_me):
     """g: dict with the ppgo_mapgraph arrays.  tracked/frame_mp/frame_me are copied and returned."""
     keep = {k: np.ascontiguousarray(v) for k, v in g.items()}

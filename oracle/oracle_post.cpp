@@ -520,6 +520,146 @@ int ppgo_window_nn(const float* q, int dim, const float* desc, const int32_t* ca
     return bi;
 }
 
+namespace {
+// Tcw * p, Pinhole::project (sensors/src/Pinhole.cpp:32-38), GeometricCamera::IsInImage (GeometricCamera.cpp:21-24)
+inline void se3_apply(const ppgo_pose* T, const float* p, float* o) {
+    for (int r = 0; r < 3; r++) o[r] = T->R[3 * r] * p[0] + T->R[3 * r + 1] * p[1] + T->R[3 * r + 2] * p[2] + T->t[r];
+}
+inline void cam_center(const ppgo_pose* T, float* ow) {  // Tcw.inverse().translation() = -R^T t
+    for (int r = 0; r < 3; r++) ow[r] = -(T->R[r] * T->t[0] + T->R[3 + r] * T->t[1] + T->R[6 + r] * T->t[2]);
+}
+inline void pinhole_project(const ppgo_cfg* c, const float* p, float* uv) {
+    uv[0] = c->K[0] * p[0] / p[2] + c->K[2];
+    uv[1] = c->K[4] * p[1] / p[2] + c->K[5];
+}
+inline bool in_image(const ppgo_grid* g, float x, float y) {
+    return x >= (float)g->minX && x < (float)g->maxX && y >= (float)g->minY && y < (float)g->maxY;
+}
+// the gates shared by :501-531, :931-969, :1060-1090
+inline bool project_gates(const ppgo_cfg* c, const ppgo_grid* g, const ppgo_pose* Tcw, const float* Ow,
+                          const ppgo_mappoints* mp, int id, float* uv) {
+    const float* pw = mp->pos + 3 * (size_t)id;
+    float pc[3];
+    se3_apply(Tcw, pw, pc);
+    if (pc[2] < 0.0f) return false;
+    pinhole_project(c, pc, uv);
+    if (!in_image(g, uv[0], uv[1])) return false;
+    const float PO[3] = {pw[0] - Ow[0], pw[1] - Ow[1], pw[2] - Ow[2]};
+    const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist < mp->min_dist[id] || dist > mp->max_dist[id]) return false;
+    const float* Pn = mp->normal + 3 * (size_t)id;
+    const float dot = PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2];
+    if ((double)dot < 0.5 * (double)dist) return false;
+    return true;
+}
+}  // namespace
+
+int ppgo_search_by_projection_frames(const ppgo_cfg* c, const ppgo_pose* Tcw, const ppgo_mappoints* mp,
+                                     int nl, const int32_t* last_mp, const uint8_t* last_outlier,
+                                     int nc, const float* cur_pos, const float* cur_desc, int32_t* cur_mp, float th) {
+    const int D = c->desc_dim;
+    const float TH_HIGH = 0.8f;
+    ppgo_grid* g = ppgo_grid_build(c, nc, cur_pos);
+    std::vector<int32_t> idx(std::max(nc, 1));
+    int nmatches = 0;
+    for (int i = 0; i < nl; i++) {
+        const int id = last_mp[i];
+        if (id < 0 || last_outlier[i]) continue;
+        float pc[3], uv[2];
+        se3_apply(Tcw, mp->pos + 3 * (size_t)id, pc);
+        const float invzc = (float)(1.0 / (double)pc[2]);  // :46: float <- double division
+        if (invzc < 0) continue;
+        pinhole_project(c, pc, uv);
+        if (!in_image(g, uv[0], uv[1])) continue;
+        const int cnt = std::min(ppgo_features_in_area(g, uv[0], uv[1], th, idx.data(), nc), nc);
+        if (cnt == 0) continue;
+        float bestDist = 1e6f;
+        int bestIdx2 = -1;
+        for (int k = 0; k < cnt; k++) {
+            const int i2 = idx[k];
+            if (cur_mp[i2] >= 0 && mp->nobs[cur_mp[i2]] > 0) continue;
+            const float dist = ppgo_descriptor_distance(mp->desc + (size_t)id * D, cur_desc + (size_t)i2 * D, D);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) { cur_mp[bestIdx2] = id; nmatches++; }
+    }
+    ppgo_grid_free(g);
+    return nmatches;
+}
+
+int ppgo_search_by_projection_sim3(const ppgo_cfg* c, const ppgo_pose* Tcw, const ppgo_mappoints* mp,
+                                   int np, const int32_t* points,
+                                   int nk, const float* kf_pos, const float* kf_desc, int32_t* matched,
+                                   int th, float ratio_hamming) {
+    const int D = c->desc_dim;
+    const float TH_LOW = 0.7f;
+    float Ow[3];
+    cam_center(Tcw, Ow);
+    std::vector<uint8_t> found(std::max(mp->m, 1), 0);  // spAlreadyFound, :487-488 (a snapshot)
+    for (int k = 0; k < nk; k++)
+        if (matched[k] >= 0) found[matched[k]] = 1;
+    ppgo_grid* g = ppgo_grid_build(c, nk, kf_pos);
+    std::vector<int32_t> idx(std::max(nk, 1));
+    int nmatches = 0;
+    for (int iMP = 0; iMP < np; iMP++) {
+        const int id = points[iMP];
+        if (mp->bad[id] || found[id]) continue;
+        float uv[2];
+        if (!project_gates(c, g, Tcw, Ow, mp, id, uv)) continue;
+        const int cnt = std::min(ppgo_features_in_area(g, uv[0], uv[1], (float)th, idx.data(), nk), nk);
+        if (cnt == 0) continue;
+        float bestDist = 1e6f;
+        int bestIdx = -1;
+        for (int k = 0; k < cnt; k++) {
+            const int i2 = idx[k];
+            if (matched[i2] >= 0) continue;
+            const float dist = ppgo_descriptor_distance(mp->desc + (size_t)id * D, kf_desc + (size_t)i2 * D, D);
+            if (dist < bestDist) { bestDist = dist; bestIdx = i2; }
+        }
+        if (bestDist <= TH_LOW * ratio_hamming) { matched[bestIdx] = id; nmatches++; }
+    }
+    ppgo_grid_free(g);
+    return nmatches;
+}
+
+int ppgo_fuse_match(const ppgo_cfg* c, const ppgo_pose* Tcw, const ppgo_mappoints* mp,
+                    int np, const int32_t* points, const uint8_t* in_kf,
+                    int nk, const float* kf_pos, const float* kf_desc, float th, int with_e2, int32_t* best_idx) {
+    const int D = c->desc_dim;
+    const float TH_LOW = 0.7f;
+    float Ow[3];
+    cam_center(Tcw, Ow);
+    ppgo_grid* g = ppgo_grid_build(c, nk, kf_pos);
+    std::vector<int32_t> idx(std::max(nk, 1));
+    int nFused = 0;
+    for (int i = 0; i < np; i++) {
+        best_idx[i] = -1;
+        const int id = points[i];
+        if (id < 0) continue;
+        if (mp->bad[id]) continue;
+        if (in_kf[i]) continue;
+        float uv[2];
+        if (!project_gates(c, g, Tcw, Ow, mp, id, uv)) continue;
+        const int cnt = std::min(ppgo_features_in_area(g, uv[0], uv[1], th, idx.data(), nk), nk);
+        if (cnt == 0) continue;
+        float bestDist = 1e6f;
+        int bestIdx = -1;
+        for (int k = 0; k < cnt; k++) {
+            const int i2 = idx[k];
+            if (with_e2) {
+                const float ex = uv[0] - kf_pos[2 * i2], ey = uv[1] - kf_pos[2 * i2 + 1];
+                const float e2 = ex * ex + ey * ey;
+                if ((double)e2 > 5.99) continue;
+            }
+            const float dist = ppgo_descriptor_distance(mp->desc + (size_t)id * D, kf_desc + (size_t)i2 * D, D);
+            if (dist < bestDist) { bestDist = dist; bestIdx = i2; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+    }
+    ppgo_grid_free(g);
+    return nFused;
+}
+
 int ppgo_extend_map_matches(const ppgo_cfg* c, float nnratio, float th, const ppgo_mapgraph* g,
                             int n, const float* desc, const float* pos_un,
                             int n_edges, const uint32_t* edge_idx,

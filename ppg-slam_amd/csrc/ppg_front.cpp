@@ -1269,6 +1269,79 @@ int ppg_features_in_area(const ppg_grid* g, float x, float y, float r, int32_t* 
     return cnt;
 }
 
+int ppg_grid_is_in_image(const ppg_grid* g, float x, float y) {
+    if (!g) return 0;
+    return x >= (float)g->minX && x < (float)g->maxX && y >= (float)g->minY && y < (float)g->maxY;
+}
+
+int ppg_match_projected(ppg_ctx* c, const ppg_proj_args* a, int32_t* best_idx, float* best_dist, int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (!a || !a->grid || a->n1 < 0 || a->n2 < 0 || a->n2 != a->grid->n || (a->n1 && (!a->desc1 || !a->uv || !a->radius || !best_idx)) ||
+        (a->n2 && !a->desc2))
+        return fail(c, PPG_EINVAL, "ppg_match_projected: bad argument");
+    if (n_matches) *n_matches = 0;
+    const int n1 = a->n1, n2 = a->n2, dim = 256;
+    for (int i = 0; i < n1; i++) { best_idx[i] = -1; if (best_dist) best_dist[i] = 1e6f; }
+    if (n1 == 0 || n2 == 0) return PPG_OK;
+    // candidate lists in GetFeaturesInArea order, the reprojection gate applied (it does not depend on the loop state)
+    std::vector<int32_t> off(n1 + 1, 0), idx, tmp(n2);
+    for (int i = 0; i < n1; i++) {
+        if (!a->row_ok || a->row_ok[i]) {
+            const float u = a->uv[2 * i], v = a->uv[2 * i + 1];
+            const int k = ppg_features_in_area(a->grid, u, v, a->radius[i], tmp.data(), n2);
+            for (int t = 0; t < k; t++) {
+                if (a->e2_max >= 0.f) {
+                    const float ex = u - a->grid->pos[2 * tmp[t]], ey = v - a->grid->pos[2 * tmp[t] + 1];
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 > a->e2_max) continue;
+                }
+                idx.push_back(tmp[t]);
+            }
+        }
+        off[i + 1] = (int32_t)idx.size();
+    }
+    const size_t nd = idx.size();
+    if (nd == 0) return PPG_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    hipStream_t s = c->post;
+    int rc = grow(c, c->mA, (size_t)n1 * dim);
+    if (!rc) rc = grow(c, c->mB, (size_t)n2 * dim);
+    if (!rc) rc = grow(c, c->mD, nd);
+    if (!rc) rc = grow(c, c->mOff, (size_t)n1 + 1);
+    if (!rc) rc = grow(c, c->mIdx, nd);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->mA.p, a->desc1, sizeof(float) * n1 * dim, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mB.p, a->desc2, sizeof(float) * n2 * dim, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mOff.p, off.data(), sizeof(int32_t) * (n1 + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mIdx.p, idx.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
+    HIPCHK(c, ppg::launch_dist_csr(c->mA.p, n1, c->mB.p, dim, c->mOff.p, c->mIdx.p, c->mD.p, s));
+    std::vector<float> D(nd);
+    HIPCHK(c, hipMemcpyAsync(D.data(), c->mD.p, sizeof(float) * nd, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    // the reference's loop, with table look-ups in place of DescriptorDistance
+    int nm = 0;
+    for (int i = 0; i < n1; i++) {
+        float best = 1e6f, second = 1e6f;
+        int bi = -1;
+        for (int k = off[i]; k < off[i + 1]; k++) {
+            const int j = idx[k];
+            if (a->slot_blocked && a->slot_blocked[j]) continue;
+            const float d = D[k];
+            if (d < best) { second = best; best = d; bi = j; }
+            else if (d < second) second = d;
+        }
+        if (best_dist) best_dist[i] = best;
+        if (best <= a->th) {
+            if (a->ratio > 0.f && best > a->ratio * second) continue;
+            best_idx[i] = bi;
+            nm++;
+            if (a->slot_blocked && a->row_claims && a->row_claims[i]) a->slot_blocked[bi] = 1;
+        }
+    }
+    if (n_matches) *n_matches = nm;
+    return PPG_OK;
+}
+
 int ppg_search_for_initialization(ppg_ctx* c, float nnratio, const float* desc1, int n1, const float* desc2, int n2,
                                   const float* pos2, float* prev, int window, int32_t* m12, int* n_matches) {
     if (!c) return PPG_EINVAL;

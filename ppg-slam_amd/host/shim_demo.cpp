@@ -1,9 +1,11 @@
 // Exercises the host-side mirror (PPGExtractor::run, Matcher::SearchForInitialization) the way
 // map/src/Frame.cpp:62 and system/src/Tracking.cpp:524-525 use the reference classes.
-// Usage: shim_demo <weights dir> <raw u8 image A> <raw u8 image B> <width> <height>
+// Usage: shim_demo <weights dir> <raw u8 image A> <raw u8 image B> <width> <height> [projection dump file]
 // Prints one line of integers that tests/test_gpu_parity.py compares with the C-ABI results.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "Matcher.h"
@@ -19,8 +21,76 @@ static std::vector<uint8_t> read_raw(const char* path, size_t n) {
     return v;
 }
 
+template <typename T>
+static void dump(FILE* f, const std::vector<T>& v) {
+    const int32_t n = (int32_t)v.size();
+    fwrite(&n, 4, 1, f);
+    if (n) fwrite(v.data(), sizeof(T), v.size(), f);
+}
+
+// The projection matchers on a synthetic map built from frame A's key points (tests/test_gpu_parity.py rebuilds
+// nothing: it reads the dumped inputs, gives them to the CPU oracle and compares the dumped results).
+static int projection_demo(Matcher& matcher, const CameraModel& cam, FrameView F[2], const char* out_path) {
+    const int na = (int)F[0].mvKeysUn.size(), nb = (int)F[1].mvKeysUn.size();
+    MapPointsView map;
+    map.desc = DescMat(na, 256);
+    for (int i = 0; i < na; i++) {
+        const float z = i % 2 == 0 ? 3.5f : 2.0f + 0.5f * (float)(i % 7);  // half of the points reproject within a pixel
+        const float x = (F[0].mvKeysUn[i].mPos[0] - cam.K[2]) / cam.K[0] * z, y = (F[0].mvKeysUn[i].mPos[1] - cam.K[5]) / cam.K[4] * z;
+        const float n = std::sqrt(x * x + y * y + z * z);
+        map.pos.insert(map.pos.end(), {x, y, z});
+        map.normal.insert(map.normal.end(), {x / n, y / n, z / n});
+        map.min_dist.push_back(n * (i % 11 == 3 ? 1.2f : 0.6f));   // some points fail the scale gate
+        map.max_dist.push_back(n * 1.8f);
+        map.bad.push_back(i % 13 == 5);
+        map.nobs.push_back(i % 4);                                  // a quarter of the points is unobserved
+        std::memcpy(map.desc.ptr(i), F[0].mDescriptors.ptr(i), sizeof(float) * 256);
+    }
+    // frame B shows frame A's content displaced by (-3, -1) px: at depth z that is a translation of (-3z/fx, -z/fy); use the
+    // mean depth, so projections land within a few pixels of the true key points
+    SE3f Tcw;
+    Tcw.t[0] = -3.0f * 3.5f / cam.K[0]; Tcw.t[1] = -1.0f * 3.5f / cam.K[4]; Tcw.t[2] = 0.01f;
+    std::vector<uint8_t> outlier(na, 0);
+    F[0].mvpMapPoints.assign(na, -1);
+    for (int i = 0; i < na; i++) {
+        if (i % 5 != 4) F[0].mvpMapPoints[i] = i;
+        outlier[i] = i % 17 == 9;
+    }
+    F[1].mvpMapPoints.assign(nb, -1);
+    for (int j = 0; j < nb; j += 9) F[1].mvpMapPoints[j] = (j * 7) % std::max(na, 1);  // some slots already taken
+    std::vector<int> cur_before(F[1].mvpMapPoints.begin(), F[1].mvpMapPoints.end());
+    FrameView cur = F[1];
+    const int n1 = matcher.SearchByProjection(cur, F[0], outlier, Tcw, map, 15.f);
+    std::vector<int> points, matched(nb, -1), matched_before;
+    for (int i = na - 1; i >= 0; i--) points.push_back(i);
+    for (int j = 0; j < nb; j += 6) matched[j] = (j * 5) % std::max(na, 1);
+    matched_before = matched;
+    const int n2 = matcher.SearchByProjection(F[1], Tcw, map, points, matched, 10, 1.0f);
+    std::vector<uint8_t> in_kf(points.size());
+    for (size_t i = 0; i < points.size(); i++) in_kf[i] = i % 10 == 7;
+    std::vector<int> fuse_pts = points, best_a, best_b;
+    for (size_t i = 0; i < fuse_pts.size(); i += 23) fuse_pts[i] = -1;
+    const int n3 = matcher.Fuse(F[1], Tcw, map, fuse_pts, in_kf, 3.f, true, best_a);
+    const int n4 = matcher.Fuse(F[1], Tcw, map, fuse_pts, in_kf, 4.f, false, best_b);
+    FILE* f = fopen(out_path, "wb");
+    if (!f) return 2;
+    std::vector<float> pose(Tcw.R, Tcw.R + 9), posb, camk(cam.K, cam.K + 9);
+    pose.insert(pose.end(), Tcw.t, Tcw.t + 3);
+    for (auto& kp : F[1].mvKeysUn) { posb.push_back(kp.mPos[0]); posb.push_back(kp.mPos[1]); }
+    std::vector<int> counts = {n1, n2, n3, n4, cam.width, cam.height};
+    dump(f, counts); dump(f, camk); dump(f, pose);
+    dump(f, map.pos); dump(f, map.normal); dump(f, map.min_dist); dump(f, map.max_dist); dump(f, map.desc.data);
+    dump(f, map.bad); dump(f, map.nobs);
+    dump(f, F[0].mvpMapPoints); dump(f, outlier); dump(f, posb); dump(f, F[1].mDescriptors.data);
+    dump(f, cur_before); dump(f, cur.mvpMapPoints);
+    dump(f, points); dump(f, matched_before); dump(f, matched);
+    dump(f, fuse_pts); dump(f, in_kf); dump(f, best_a); dump(f, best_b);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc != 6) { fprintf(stderr, "usage: %s weights_dir imgA imgB W H\n", argv[0]); return 2; }
+    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s weights_dir imgA imgB W H [projection dump]\n", argv[0]); return 2; }
     const int W = atoi(argv[4]), H = atoi(argv[5]);
     CameraModel cam;
     cam.width = W; cam.height = H;
@@ -45,6 +115,7 @@ int main(int argc, char** argv) {
         size_t conn = 0;
         for (auto& kp : F[0].mvKeysUn) conn += kp.mvConnected.size();
         printf("%zu %zu %zu %zu %d %lld\n", F[0].mvKeysUn.size(), F[0].mvKeyEdges.size(), F[1].mvKeysUn.size(), conn, nm, chk);
+        if (argc == 7 && projection_demo(matcher, cam, F, argv[6]) != 0) { fprintf(stderr, "cannot write %s\n", argv[6]); return 2; }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

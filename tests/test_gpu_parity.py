@@ -429,3 +429,63 @@ def test_host_mirror_program(pkg, synth, tmp_path):
         ref -= 1 << 64
     assert (n0, e0, n1, conn0, nm) == (r0["n"], r0["n_edges"], r1["n"], len(r0["conn_idx"]), cnt)
     assert chk == ref
+
+
+def _read_dump(path):
+    import struct
+    data = open(path, "rb").read()
+    ofs = 0
+    dtypes = [np.int32, np.float32, np.float32,                                       # counts, K, pose
+              np.float32, np.float32, np.float32, np.float32, np.float32, np.uint8, np.int32,   # map
+              np.int32, np.uint8, np.float32, np.float32,                               # last_mp, outlier, pos B, desc B
+              np.int32, np.int32, np.int32, np.int32, np.int32, np.int32, np.uint8, np.int32, np.int32]
+    out = []
+    for dt in dtypes:
+        (n,) = struct.unpack_from("<i", data, ofs)
+        ofs += 4
+        nbytes = n * np.dtype(dt).itemsize
+        out.append(np.frombuffer(data, dt, n, ofs).copy())
+        ofs += nbytes
+    assert ofs == len(data)
+    return out
+
+
+def test_host_mirror_projection_matchers_vs_oracle(pkg, orc, synth, tmp_path):
+    """Matcher::SearchByProjection (frame/frame and key-frame/Sim3) and both Fuse variants of the C++ mirror, which
+    take every candidate distance from the GPU, against the line-by-line CPU restatement on the same synthetic map."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "ppg-slam_amd", "host", "shim_demo")
+    assert os.path.exists(demo), "build it with make -C ppg-slam_amd/csrc demo"
+    H, W = 480, 640
+    imgs = [synth.make_frame(H, W, 61, t, "sparse") for t in (0, 1)]
+    paths = []
+    for k, im in enumerate(imgs):
+        p = tmp_path / f"img{k}.raw"
+        p.write_bytes(im.tobytes())
+        paths.append(str(p))
+    dump = str(tmp_path / "proj.bin")
+    out = subprocess.run([demo, os.path.dirname(pkg.DEFAULT_WEIGHTS), paths[0], paths[1], str(W), str(H), dump],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    (counts, K, pose, pos, normal, dmin, dmax, desc, bad, nobs, last_mp, outlier, posb, descb, cur_before, cur_after,
+     points, matched_before, matched_after, fuse_pts, in_kf, best_a, best_b) = _read_dump(dump)
+    n1, n2, n3, n4, Wd, Hd = [int(v) for v in counts]
+    assert (Wd, Hd) == (W, H) and len(bad) > 100 and len(posb) // 2 > 100
+    cfg = orc.default_cfg(W, H)
+    for k in range(9):
+        cfg.K[k] = float(K[k])
+    mp = {"pos": pos.reshape(-1, 3), "normal": normal.reshape(-1, 3), "min_dist": dmin, "max_dist": dmax,
+          "desc": desc.reshape(-1, 256), "bad": bad, "nobs": nobs}
+    R, t = pose[:9], pose[9:]
+    posb = posb.reshape(-1, 2)
+    descb = descb.reshape(-1, 256)
+    o1, cur = orc.search_by_projection_frames(cfg, R, t, mp, last_mp, outlier, posb, descb, cur_before, 15.0)
+    assert o1 == n1 and o1 > 20 and np.array_equal(cur, cur_after)
+    o2, m = orc.search_by_projection_sim3(cfg, R, t, mp, points, posb, descb, matched_before, 10, 1.0)
+    assert o2 == n2 and o2 > 20 and np.array_equal(m, matched_after)
+    o3, ba = orc.fuse_match(cfg, R, t, mp, fuse_pts, in_kf, posb, descb, 3.0, True)
+    assert o3 == n3 and o3 > 5 and np.array_equal(ba, best_a)
+    o4, bb = orc.fuse_match(cfg, R, t, mp, fuse_pts, in_kf, posb, descb, 4.0, False)
+    assert o4 == n4 and o4 >= o3 and np.array_equal(bb, best_b)

@@ -176,3 +176,79 @@ def test_extend_map_matches_small_graph(orc):
     assert list(fmp[:4]) == [0, 1, -1, 3]
     assert list(fme) == [0, -1, 2]
     assert cnt == 2 and list(tracked) == [1, 1, 0, 1]
+
+
+def _tiny_map(nobs0):
+    """Three map points at depth 1 in front of an identity camera (fx = fy = 100, c = (32, 24))."""
+    uv = np.array([[20.0, 20.0], [22.0, 21.0], [50.0, 40.0]], np.float32)
+    pos = np.stack([(uv[:, 0] - 32) / 100, (uv[:, 1] - 24) / 100, np.ones(3)], 1).astype(np.float32)
+    desc = np.zeros((3, 256), np.float32)
+    desc[0, 0] = 1.0
+    desc[1, 0], desc[1, 1] = 0.8, 0.6      # 0.632 from e0, 0.894 from e1
+    desc[2, 2] = 1.0
+    nrm = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    d = np.linalg.norm(pos, axis=1).astype(np.float32)
+    return uv, {"pos": pos, "normal": nrm.astype(np.float32), "min_dist": 0.5 * d, "max_dist": 2 * d, "desc": desc,
+                "bad": np.zeros(3, np.uint8), "nobs": np.array([nobs0, 0, 1], np.int32)}
+
+
+def _tiny_cfg(orc):
+    cfg = orc.default_cfg(64, 48)
+    for k, v in enumerate([100, 0, 32, 0, 100, 24, 0, 0, 1]):
+        cfg.K[k] = float(v)
+    return cfg
+
+
+def test_search_by_projection_claim_and_overwrite(orc):
+    """Matcher.cpp:31-87: a slot taken by an observed map point is skipped by later rows (:67-69); a slot taken by an
+    unobserved one is overwritten (:80)."""
+    cfg = _tiny_cfg(orc)
+    cur_pos = np.array([[21.0, 20.0], [23.0, 22.0]], np.float32)
+    cur_desc = np.zeros((2, 256), np.float32)
+    cur_desc[0, 0] = 1.0
+    cur_desc[1, 1] = 1.0
+    R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    last_mp, outl = np.array([0, 1, 2], np.int32), np.zeros(3, np.uint8)
+    _, mp = _tiny_map(1)
+    n, cur = orc.search_by_projection_frames(cfg, R, t, mp, last_mp, outl, cur_pos, cur_desc, np.full(2, -1, np.int32), 15.0)
+    assert n == 1 and cur.tolist() == [0, -1]          # row 1 finds slot 0 blocked and slot 1 too far (0.894 > 0.8)
+    _, mp = _tiny_map(0)
+    n, cur = orc.search_by_projection_frames(cfg, R, t, mp, last_mp, outl, cur_pos, cur_desc, np.full(2, -1, np.int32), 15.0)
+    assert n == 2 and cur.tolist() == [1, -1]          # row 1 overwrites row 0's unobserved point
+    # outliers and points behind the camera are skipped
+    n, cur = orc.search_by_projection_frames(cfg, R, t, mp, last_mp, np.array([1, 0, 0], np.uint8), cur_pos, cur_desc,
+                                             np.full(2, -1, np.int32), 15.0)
+    assert n == 1 and cur.tolist() == [1, -1]
+    n, cur = orc.search_by_projection_frames(cfg, R, np.array([0, 0, -2], np.float32), mp, last_mp, outl, cur_pos, cur_desc,
+                                             np.full(2, -1, np.int32), 15.0)
+    assert n == 0
+
+
+def test_sim3_projection_and_fuse_gates(orc):
+    """Matcher.cpp:479-568 and :897-1135: already-found points and matched slots are skipped, the scale and viewing
+    angle gates hold, Fuse's reprojection gate (e^2 <= 5.99) applies only to the first variant."""
+    cfg = _tiny_cfg(orc)
+    uv, mp = _tiny_map(1)
+    kf_pos = np.array([[21.0, 20.0], [23.0, 22.0], [50.0, 43.0]], np.float32)
+    kf_desc = np.zeros((3, 256), np.float32)
+    kf_desc[0, 0] = 1.0
+    kf_desc[1, 1] = 1.0
+    kf_desc[2, 2] = 1.0
+    R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    pts = np.array([0, 1, 2], np.int32)
+    n, m = orc.search_by_projection_sim3(cfg, R, t, mp, pts, kf_pos, kf_desc, np.full(3, -1, np.int32), 10, 1.0)
+    assert n == 2 and m.tolist() == [0, -1, 2]           # point 1: slot 0 taken, slot 1 too far (0.894 > 0.7)
+    # point 0 already found in another slot: skipped; slot 0 stays free for point 1 (0.632 <= 0.7)
+    n, m = orc.search_by_projection_sim3(cfg, R, t, mp, pts, kf_pos, kf_desc, np.array([-1, 0, -1], np.int32), 10, 1.0)
+    assert m.tolist() == [1, 0, 2] and n == 2
+    # Fuse: point 2 projects 3 px from its key point: inside the window, outside e^2 <= 5.99
+    n, b = orc.fuse_match(cfg, R, t, mp, pts, np.zeros(3, np.uint8), kf_pos, kf_desc, 4.0, True)
+    assert b.tolist() == [0, 0, -1] and n == 2
+    n, b = orc.fuse_match(cfg, R, t, mp, pts, np.zeros(3, np.uint8), kf_pos, kf_desc, 4.0, False)
+    assert b.tolist() == [0, 0, 2] and n == 3
+    # IsInKeyFrame, nullptr, scale gate
+    mp2 = dict(mp)
+    mp2["min_dist"] = mp["min_dist"].copy()
+    mp2["min_dist"][1] = 5.0
+    n, b = orc.fuse_match(cfg, R, t, mp2, np.array([0, 1, -1], np.int32), np.array([1, 0, 0], np.uint8), kf_pos, kf_desc, 4.0, False)
+    assert b.tolist() == [-1, -1, -1] and n == 0
