@@ -217,6 +217,14 @@ typedef struct ppg_proj_args {
 } ppg_proj_args;
 int ppg_match_projected(ppg_ctx* ctx, const ppg_proj_args* args, int32_t* best_idx, float* best_dist, int* n_matches);
 
+/* MapPoint::ComputeDistinctiveDescriptors (feature/src/MapPoint.cpp:234-302) for P map points at once.  desc holds
+ * the observed descriptors of all points back to back (the rows the reference pushes into vDescriptors, :253-263, in
+ * map order); point p owns rows seg_off[p] .. seg_off[p+1]-1.  All pair distances of a point come from one GPU
+ * launch; per row the median vDists[0.5*(N-1)] of the sorted row (:288-290) and the first row whose median is below
+ * the running best (initially 1.0, :284-295) are taken on the host.  best[p] = row index inside the point's segment
+ * (0 for an empty or single-row segment, as BestIdx starts at 0). */
+int ppg_distinctive_descriptors(ppg_ctx* ctx, const float* desc, const int32_t* seg_off, int n_points, int32_t* best);
+
 /* Matcher::ExtendMapMatches (matching/include/Matcher.h:54, Matcher.cpp:203-381) on flattened state.
  * Map points are numbered 0..m-1 in vpMapPoints order.  Per point: descriptor, mTrackProjX/Y,
  * mTrackViewCos, mbTrackInView, isBad(), Observations(), and getEdges() as CSR entries carrying the

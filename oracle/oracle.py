@@ -178,6 +178,13 @@ def search_for_initialization(cfg, nnratio, desc1, desc2, pos2, prev_matched, wi
     return cnt, m12, prev
 
 
+def distinctive_descriptor(desc):
+    desc = np.ascontiguousarray(desc, np.float32)
+    L = lib()
+    L.ppgo_distinctive_descriptor.restype = C.c_int
+    return int(L.ppgo_distinctive_descriptor(_p(desc), int(desc.shape[0]), int(desc.shape[1]) if desc.ndim == 2 else 256))
+
+
 class Pose(C.Structure):
     _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3)]
 

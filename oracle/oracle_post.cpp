@@ -660,6 +660,29 @@ int ppgo_fuse_match(const ppgo_cfg* c, const ppgo_pose* Tcw, const ppgo_mappoint
     return nFused;
 }
 
+int ppgo_distinctive_descriptor(const float* desc, int n, int dim) {
+    if (n <= 0) return 0;
+    const size_t N = (size_t)n;
+    std::vector<float> Distances(N * N);
+    for (size_t i = 0; i < N; i++) {
+        Distances[i * N + i] = 0;
+        for (size_t j = i + 1; j < N; j++) {
+            float distij = ppgo_descriptor_distance(desc + i * dim, desc + j * dim, dim);
+            Distances[i * N + j] = distij;
+            Distances[j * N + i] = distij;
+        }
+    }
+    float BestMedian = 1.0f;
+    int BestIdx = 0;
+    for (size_t i = 0; i < N; i++) {
+        std::vector<float> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+        std::sort(vDists.begin(), vDists.end());
+        float median = vDists[(size_t)(0.5 * (N - 1))];
+        if (median < BestMedian) { BestMedian = median; BestIdx = (int)i; }
+    }
+    return BestIdx;
+}
+
 int ppgo_extend_map_matches(const ppgo_cfg* c, float nnratio, float th, const ppgo_mapgraph* g,
                             int n, const float* desc, const float* pos_un,
                             int n_edges, const uint32_t* edge_idx,

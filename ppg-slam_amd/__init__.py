@@ -292,6 +292,14 @@ class Context:
         names = ("conv3x3", "conv_other", "conv1a", "post", "match", "host_wait", "host_tail", "host_submit", "host_finish", "host_tail_frames")
         return {k: (ms[i], launches[i]) for i, k in enumerate(names)}
 
+    def distinctive_descriptors(self, desc, seg_off):
+        """MapPoint::ComputeDistinctiveDescriptors for every segment of `desc` rows; returns BestIdx per segment."""
+        desc = np.ascontiguousarray(desc, np.float32)
+        seg = np.ascontiguousarray(seg_off, np.int32)
+        best = np.zeros(max(len(seg) - 1, 0), np.int32)
+        self._chk(self.L.ppg_distinctive_descriptors(C.c_void_p(self.h), _p(desc), _p(seg), len(seg) - 1, _p(best)))
+        return best
+
     def features_in_area(self, pos, x, y, r):
         pos = np.ascontiguousarray(pos, np.float32)
         n = pos.shape[0]

@@ -1269,6 +1269,57 @@ int ppg_features_in_area(const ppg_grid* g, float x, float y, float r, int32_t* 
     return cnt;
 }
 
+int ppg_distinctive_descriptors(ppg_ctx* c, const float* desc, const int32_t* seg_off, int P, int32_t* best) {
+    if (!c) return PPG_EINVAL;
+    if (P < 0 || (P && (!seg_off || !best))) return fail(c, PPG_EINVAL, "ppg_distinctive_descriptors: bad argument");
+    if (P == 0) return PPG_OK;
+    if (seg_off[0] != 0) return fail(c, PPG_EINVAL, "seg_off[0] must be 0");
+    for (int p = 0; p < P; p++)
+        if (seg_off[p + 1] < seg_off[p]) return fail(c, PPG_EINVAL, "seg_off must be non-decreasing");
+    const int rows = seg_off[P], dim = 256;
+    if (rows && !desc) return fail(c, PPG_EINVAL, "ppg_distinctive_descriptors: desc is null");
+    for (int p = 0; p < P; p++) best[p] = 0;
+    if (rows == 0) return PPG_OK;
+    // row i of point p is compared with every row of p: a block-diagonal candidate list
+    std::vector<int32_t> off((size_t)rows + 1, 0), idx;
+    for (int p = 0; p < P; p++)
+        for (int i = seg_off[p]; i < seg_off[p + 1]; i++) {
+            for (int j = seg_off[p]; j < seg_off[p + 1]; j++) idx.push_back(j);
+            off[(size_t)i + 1] = (int32_t)idx.size();
+        }
+    const size_t nd = idx.size();
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    hipStream_t s = c->post;
+    int rc = grow(c, c->mA, (size_t)rows * dim);
+    if (!rc) rc = grow(c, c->mD, nd);
+    if (!rc) rc = grow(c, c->mOff, (size_t)rows + 1);
+    if (!rc) rc = grow(c, c->mIdx, nd);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->mA.p, desc, sizeof(float) * rows * dim, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mOff.p, off.data(), sizeof(int32_t) * ((size_t)rows + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mIdx.p, idx.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
+    HIPCHK(c, ppg::launch_dist_csr(c->mA.p, rows, c->mA.p, dim, c->mOff.p, c->mIdx.p, c->mD.p, s));
+    std::vector<float> D(nd);
+    HIPCHK(c, hipMemcpyAsync(D.data(), c->mD.p, sizeof(float) * nd, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::vector<float> v;
+    for (int p = 0; p < P; p++) {
+        const int N = seg_off[p + 1] - seg_off[p];
+        float BestMedian = 1.0f;  // feature/src/MapPoint.cpp:284
+        int BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            const float* row = D.data() + off[(size_t)seg_off[p] + i];
+            v.assign(row, row + N);
+            v[i] = 0.f;  // :274 (the kernel's own value is sqrt(0) = 0 as well)
+            std::sort(v.begin(), v.end());
+            const float median = v[(size_t)(0.5 * (double)(N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best[p] = BestIdx;
+    }
+    return PPG_OK;
+}
+
 int ppg_grid_is_in_image(const ppg_grid* g, float x, float y) {
     if (!g) return 0;
     return x >= (float)g->minX && x < (float)g->maxX && y >= (float)g->minY && y < (float)g->maxY;

@@ -489,3 +489,22 @@ def test_host_mirror_projection_matchers_vs_oracle(pkg, orc, synth, tmp_path):
     assert o3 == n3 and o3 > 5 and np.array_equal(ba, best_a)
     o4, bb = orc.fuse_match(cfg, R, t, mp, fuse_pts, in_kf, posb, descb, 4.0, False)
     assert o4 == n4 and o4 >= o3 and np.array_equal(bb, best_b)
+
+
+def test_distinctive_descriptors_vs_oracle(pkg, orc):
+    """MapPoint::ComputeDistinctiveDescriptors batched over 60 map points with 0..12 observations each."""
+    rng = np.random.default_rng(5)
+    ctx = get_ctx(pkg, 128, 96)
+    segs, rows = [0], []
+    for p in range(60):
+        k = int(rng.integers(0, 13))
+        centre = rng.standard_normal(256).astype(np.float32)
+        for _ in range(k):
+            v = centre + (0.15 if p % 3 else 2.0) * rng.standard_normal(256).astype(np.float32)
+            rows.append(v / np.linalg.norm(v))
+        segs.append(len(rows))
+    desc = np.stack(rows).astype(np.float32)
+    best = ctx.distinctive_descriptors(desc, segs)
+    ref = [orc.distinctive_descriptor(desc[segs[p]:segs[p + 1]]) if segs[p + 1] > segs[p] else 0 for p in range(60)]
+    assert best.tolist() == ref
+    assert len(set(ref)) > 3

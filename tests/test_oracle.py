@@ -252,3 +252,16 @@ def test_sim3_projection_and_fuse_gates(orc):
     mp2["min_dist"][1] = 5.0
     n, b = orc.fuse_match(cfg, R, t, mp2, np.array([0, 1, -1], np.int32), np.array([1, 0, 0], np.uint8), kf_pos, kf_desc, 4.0, False)
     assert b.tolist() == [-1, -1, -1] and n == 0
+
+
+def test_distinctive_descriptor_known_answer(orc):
+    """feature/src/MapPoint.cpp:268-296: the row with the least median distance; BestMedian starts at 1.0, so
+    when every median is >= 1 row 0 stays."""
+    e = np.eye(256, dtype=np.float32)
+    # four observations along a line and one far away; median = third smallest of the sorted row (N = 5, own 0 included):
+    # row 0 -> 0.057, rows 1 and 2 -> 0.028 (the first of them wins), row 3 -> 0.057
+    d = np.stack([e[0], e[0] * 0.98 + e[1] * 0.02, e[0] * 0.96 + e[1] * 0.04, e[0] * 0.94 + e[1] * 0.06, e[5]])
+    assert orc.distinctive_descriptor(d) == 1
+    assert orc.distinctive_descriptor(np.stack([e[0], e[1], e[2]])) == 0      # all medians sqrt(2) >= 1
+    assert orc.distinctive_descriptor(e[:1]) == 0
+    assert orc.distinctive_descriptor(np.stack([e[3], e[3]])) == 0            # N = 2: median = vDists[0] = 0 < 1
