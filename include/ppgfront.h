@@ -126,7 +126,8 @@ enum ppg_tensor {
     PPG_T_DESCMAP = 3,   /* descriptors [h][w][256]          (:155) */
     PPG_T_SCORE = 4,     /* junc_pred   [H][W]               (:162) */
     PPG_T_HEAT = 5,      /* heatmap_score [H][W] before refineHeatMap (:242) */
-    PPG_T_HEAT_REFINED = 6 /* after refineHeatMap            (:243-256) */
+    PPG_T_HEAT_REFINED = 6, /* after refineHeatMap            (:243-256) */
+    PPG_T_HEAT_REMAPPED = 7 /* after cv::remap, exists only when D[0] != 0 (:261-262); read-only */
 };
 size_t ppg_tensor_elems(const ppg_ctx* ctx, int which);
 int ppg_read_tensor(ppg_ctx* ctx, int which, int frame, float* dst, size_t n_elems);

@@ -281,6 +281,21 @@ def extend_map_matches(cfg, nnratio, th, g, desc, pos_un, edge_idx, conn_off, co
     return cnt, tracked, frame_mp, frame_me
 
 
+def remap_heat(cfg, heat):
+    """cv::remap of the refined heat map through the undistortion maps (PPGExtractor.cpp:261-262)."""
+    src = np.ascontiguousarray(heat, np.float32)
+    dst = np.empty_like(src)
+    lib().ppgo_remap_heat(C.byref(cfg), _p(src), _p(dst))
+    return dst
+
+
+def undistort_maps(cfg):
+    mx = np.empty((cfg.height, cfg.width), np.float32)
+    my = np.empty((cfg.height, cfg.width), np.float32)
+    lib().ppgo_undistort_maps(C.byref(cfg), _p(mx), _p(my))
+    return mx, my
+
+
 def extract(net, cfg, img):
     """Full reference pipeline PPGExtractor::run (PPGExtractor.cpp:118-147) on one image."""
     t = net.inference(img)
@@ -291,6 +306,8 @@ def extract(net, cfg, img):
         return res
     prob = heat_prob(t["heat"])
     refined = refine_heat(cfg, prob)
+    if cfg.D[0] != 0.0:
+        refined = remap_heat(cfg, refined)
     res["heat"] = refined
     res.update(detect_lines(cfg, refined, kp["un"], kp["out"]))
     res["desc"] = gen_descriptors(cfg, t["desc"], kp["xy"])

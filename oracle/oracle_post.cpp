@@ -233,6 +233,72 @@ int ppgo_detect_keypoints(const ppgo_cfg* c, const float* score, int32_t* kp_xy,
     return n;
 }
 
+void ppgo_undistort_maps(const ppgo_cfg* c, float* mapx, float* mapy) {
+    const int W = c->width, H = c->height;
+    const double fx = c->K[0], fy = c->K[4], u0 = c->K[2], v0 = c->K[5];
+    // inverse of the upper-triangular camera matrix
+    const double ir[9] = {1.0 / fx, 0.0, -u0 / fx, 0.0, 1.0 / fy, -v0 / fy, 0.0, 0.0, 1.0};
+    for (int i = 0; i < H; i++) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < W; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            double u, v;
+            if (!c->fisheye) {
+                const double k1 = c->D[0], k2 = c->D[1], p1 = c->D[2], p2 = c->D[3], k3 = 0.0;
+                const double w = 1. / _w, x = _x * w, y = _y * w;
+                const double x2 = x * x, y2 = y * y;
+                const double r2 = x2 + y2, _2xy = 2 * x * y;
+                const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+                const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+                const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+                u = fx * xd + u0;
+                v = fy * yd + v0;
+            } else {
+                const double x = _x / _w, y = _y / _w;
+                const double r = std::sqrt(x * x + y * y);
+                const double theta = std::atan(r);
+                const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+                const double theta_d = theta * (1 + c->D[0] * theta2 + c->D[1] * theta4 + c->D[2] * theta6 + c->D[3] * theta8);
+                const double scale = (r == 0) ? 1.0 : theta_d / r;
+                u = fx * x * scale + u0;
+                v = fy * y * scale + v0;
+            }
+            mapx[(size_t)i * W + j] = (float)u;
+            mapy[(size_t)i * W + j] = (float)v;
+        }
+    }
+}
+
+void ppgo_remap_heat(const ppgo_cfg* c, const float* src, float* dst) {
+    const int W = c->width, H = c->height;
+    std::vector<float> mx((size_t)W * H), my((size_t)W * H);
+    ppgo_undistort_maps(c, mx.data(), my.data());
+    const int INTER_BITS = 5, INTER_TAB_SIZE = 1 << INTER_BITS;
+    // bilinear weight table, as initInterTab2D builds it for float data
+    std::vector<float> tab((size_t)INTER_TAB_SIZE * INTER_TAB_SIZE * 4);
+    const float scale = 1.f / INTER_TAB_SIZE;
+    for (int i = 0; i < INTER_TAB_SIZE; i++)
+        for (int j = 0; j < INTER_TAB_SIZE; j++) {
+            const float vy[2] = {1.f - i * scale, i * scale}, vx[2] = {1.f - j * scale, j * scale};
+            float* w = &tab[((size_t)i * INTER_TAB_SIZE + j) * 4];
+            for (int k1 = 0; k1 < 2; k1++)
+                for (int k2 = 0; k2 < 2; k2++) w[k1 * 2 + k2] = vy[k1] * vx[k2];
+        }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const int sx = (int)std::lrint((double)(mx[p] * (float)INTER_TAB_SIZE));  // cvRound
+            const int sy = (int)std::lrint((double)(my[p] * (float)INTER_TAB_SIZE));
+            const float* w = &tab[((size_t)(sy & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (sx & (INTER_TAB_SIZE - 1))) * 4];
+            const int x0 = sx >> INTER_BITS, y0 = sy >> INTER_BITS;
+            float v[4];
+            for (int k = 0; k < 4; k++) {
+                const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+                v[k] = (xx >= 0 && yy >= 0 && xx < W && yy < H) ? src[(size_t)yy * W + xx] : 0.f;
+            }
+            dst[p] = v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+        }
+}
+
 void ppgo_refine_heat(const ppgo_cfg* c, float* heat) {
     const int W = c->width, H = c->height, S = c->heatmap_refine_sz;
     const int gx = W / S, gy = H / S;

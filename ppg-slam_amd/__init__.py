@@ -17,7 +17,7 @@ DEFAULT_WEIGHTS = os.path.join(_HERE, "weights", "ppg_weights.bin")
 HEADER = os.path.join(_HERE, "..", "include", "ppgfront.h")
 
 PPG_OK, PPG_EINVAL, PPG_EHIP, PPG_EIO, PPG_ENOMEM, PPG_ECAP = 0, -1, -2, -3, -4, -5
-T_FEAT, T_JUNC, T_HEAT_RAW, T_DESCMAP, T_SCORE, T_HEAT, T_HEAT_REFINED = range(7)
+T_FEAT, T_JUNC, T_HEAT_RAW, T_DESCMAP, T_SCORE, T_HEAT, T_HEAT_REFINED, T_HEAT_REMAPPED = range(8)
 MATCH_PLAIN, MATCH_INIT = 0, 1
 
 
@@ -219,7 +219,8 @@ class Context:
         self._chk(self.L.ppg_read_tensor(C.c_void_p(self.h), which, frame, _p(a), C.c_size_t(n)))
         h, w = self.H // 8, self.W // 8
         shape = {T_FEAT: (h, w, 128), T_JUNC: (h, w, 65), T_HEAT_RAW: (self.H, self.W, 2), T_DESCMAP: (h, w, 256),
-                 T_SCORE: (self.H, self.W), T_HEAT: (self.H, self.W), T_HEAT_REFINED: (self.H, self.W)}[which]
+                 T_SCORE: (self.H, self.W), T_HEAT: (self.H, self.W), T_HEAT_REFINED: (self.H, self.W),
+                 T_HEAT_REMAPPED: (self.H, self.W)}[which]
         return a.reshape(shape)
 
     def write_tensor(self, which, arr, frame=0):

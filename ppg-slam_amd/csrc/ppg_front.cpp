@@ -108,6 +108,7 @@ struct ppg_ctx {
     float *a1 = nullptr, *p1 = nullptr, *a2 = nullptr, *p2 = nullptr, *a3 = nullptr, *p3 = nullptr, *a4 = nullptr,
           *feat = nullptr, *pa_o = nullptr, *junc = nullptr, *da_o = nullptr, *descmap = nullptr, *hs0 = nullptr,
           *hs1 = nullptr, *hs2 = nullptr, *heat_raw = nullptr, *prob = nullptr, *refined = nullptr, *score = nullptr;
+    float *mapx = nullptr, *mapy = nullptr, *remapped = nullptr;  // lens: undistortion maps and the remapped heat map (D[0] != 0 only)
     uint8_t* state = nullptr;
     uint32_t *resid = nullptr, *kept = nullptr;
     unsigned long long* kept_key = nullptr;
@@ -444,6 +445,39 @@ int pick_tile(const DevConv& dc, int H, int W, int mode) {
     return a16 < a32 ? 16 : 32;
 }
 
+// cv::initUndistortRectifyMap / cv::fisheye::initUndistortRectifyMap (K, D, R = I, P = K, CV_32F maps) of
+// feature/src/PPGExtractor.cpp:65-71, after OpenCV's published algorithm: per destination pixel the normalised
+// coordinate (accumulated along the row in double, as OpenCV does), the forward distortion model, back to pixels.
+void undistort_rectify_maps(const ppg_config& c, std::vector<float>& mx, std::vector<float>& my) {
+    const int W = c.width, H = c.height;
+    mx.resize((size_t)W * H); my.resize((size_t)W * H);
+    const double fx = c.K[0], fy = c.K[4], cx = c.K[2], cy = c.K[5];
+    const double ir0 = 1.0 / fx, ir2 = -cx / fx, ir4 = 1.0 / fy, ir5 = -cy / fy;
+    for (int i = 0; i < H; i++) {
+        double _x = ir2, _y = i * ir4 + ir5;
+        for (int j = 0; j < W; j++, _x += ir0) {
+            const double x = _x, y = _y;
+            double u, v;
+            if (!c.fisheye) {
+                const double k1 = c.D[0], k2 = c.D[1], p1 = c.D[2], p2 = c.D[3];
+                const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+                const double kr = 1 + ((0.0 * r2 + k2) * r2 + k1) * r2;
+                const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+                const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+                u = fx * xd + cx; v = fy * yd + cy;
+            } else {
+                const double r = std::sqrt(x * x + y * y), theta = std::atan(r);
+                const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+                const double theta_d = theta * (1 + c.D[0] * t2 + c.D[1] * t4 + c.D[2] * t6 + c.D[3] * t8);
+                const double scale = r == 0 ? 1.0 : theta_d / r;
+                u = fx * x * scale + cx; v = fy * y * scale + cy;
+            }
+            mx[(size_t)i * W + j] = (float)u;
+            my[(size_t)i * W + j] = (float)v;
+        }
+    }
+}
+
 ppg::ConvGroup conv_group(const DevConv& dc, float* out, int mode, int relu, int nblk0) {
     ppg::ConvGroup g;
     g.out = out; g.bias = dc.bias; g.alpha = dc.alpha; g.beta = dc.beta;
@@ -515,6 +549,7 @@ size_t tensor_elems(const ppg_ctx* c, int which) {
         case PPG_T_HEAT_RAW: return HW * 2;
         case PPG_T_DESCMAP: return hw * 256;
         case PPG_T_SCORE: case PPG_T_HEAT: case PPG_T_HEAT_REFINED: return HW;
+        case PPG_T_HEAT_REMAPPED: return c->remapped ? HW : 0;
         default: return 0;
     }
 }
@@ -527,6 +562,7 @@ float* tensor_ptr(ppg_ctx* c, int which) {
         case PPG_T_SCORE: return c->score;
         case PPG_T_HEAT: return c->prob;
         case PPG_T_HEAT_REFINED: return c->refined;
+        case PPG_T_HEAT_REMAPPED: return c->remapped;
         default: return nullptr;
     }
 }
@@ -644,6 +680,14 @@ static int create_impl(ppg_ctx* c) {
     DA(heat_raw, B * HW * 2);
     DA(prob, B * HW);
     DA(refined, B * HW);
+    if (c->cfg.D[0] != 0.0f) {  // feature/src/PPGExtractor.cpp:261: the heat map is remapped only then
+        std::vector<float> mx, my;
+        undistort_rectify_maps(c->cfg, mx, my);
+        rc = upload(c, &c->mapx, mx);
+        if (!rc) rc = upload(c, &c->mapy, my);
+        if (rc) return rc;
+        DA(remapped, B * HW);
+    }
     DA(score, B * HW);
     DA(state, B * HW);
     c->resid_cap = (int)HW;
@@ -820,16 +864,19 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    if (c->cfg.D[0] != 0.0f)
-        return fail(c, PPG_EINVAL, "heat-map remap for D[0] != 0 (PPGExtractor.cpp:261-262) is not built");
     HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
     ProfScope ps(c, PPG_PROF_POST, c->post);
     ppg::HeatArgs ha = heat_args(c, n);
     // last layer of EdgeHeatmap (1x1 conv 4->2, heatmap_decoder.py:22) fused with the 2-way softmax of :242
     if (!c->skip_heat) HIPCHK(c, ppg::launch_heat_tail(ha, c->post));
     if (!c->skip_refine) HIPCHK(c, ppg::launch_refine(ha, c->post));
+    if (c->remapped) {  // undistort the heat map (PPGExtractor.cpp:261-262)
+        ppg::RemapArgs ra;
+        ra.src = c->refined; ra.dst = c->remapped; ra.mapx = c->mapx; ra.mapy = c->mapy; ra.B = n; ra.H = c->H; ra.W = c->W;
+        HIPCHK(c, ppg::launch_remap(ra, c->post));
+    }
     ppg::LineArgs la;
-    la.heat = c->refined; la.kp_un = c->kp_un; la.kp_out = c->kp_out; la.counters = c->counters;
+    la.heat = c->remapped ? c->remapped : c->refined; la.kp_un = c->kp_un; la.kp_out = c->kp_out; la.counters = c->counters;
     la.row_cnt = c->row_cnt; la.cand_ij = c->cand_ij; la.cand_sc = c->cand_sc; la.cand_cap = c->cand_cap;
     la.B = n; la.H = c->H; la.W = c->W; la.max_num = c->maxn;
     la.heat_thresh = c->cfg.line_heatmap_thresh;

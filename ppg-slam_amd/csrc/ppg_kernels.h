@@ -85,6 +85,15 @@ struct HeatArgs {
     int refine_sz;
     float valid_thresh, valid_ratio;
 };
+// cv::remap(heat, heat, mX, mY, INTER_LINEAR) of feature/src/PPGExtractor.cpp:261-262 (BORDER_CONSTANT 0)
+struct RemapArgs {
+    const float* src;   // [B][H][W]
+    float* dst;         // [B][H][W]
+    const float* mapx;  // [H][W]
+    const float* mapy;
+    int B, H, W;
+};
+hipError_t launch_remap(const RemapArgs& a, hipStream_t s);
 hipError_t launch_heat_tail(const HeatArgs& a, hipStream_t s);
 hipError_t launch_heat_prob_from_raw(const HeatArgs& a, hipStream_t s);
 hipError_t launch_refine(const HeatArgs& a, hipStream_t s);

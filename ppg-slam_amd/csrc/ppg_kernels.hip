@@ -706,6 +706,31 @@ hipError_t launch_heat_prob_from_raw(const HeatArgs& a, hipStream_t s) {
 }
 
 // =====================================================================================
+// cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) of a float image through float maps, as OpenCV's generic path
+// evaluates it: the map coordinate is rounded to 1/32 pixel (cvRound(m * INTER_TAB_SIZE), ties to even), the
+// four weights are float products of (1 - a, a) with a = k/32, and the sum runs tap by tap from the left.
+// =====================================================================================
+__global__ __launch_bounds__(256) void remap_kernel(RemapArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hw = (long)a.H * a.W;
+    if (i >= hw * a.B) return;
+    const long p = i % hw;
+    const float* src = a.src + (i - p);
+    const int sx = (int)rintf(a.mapx[p] * 32.0f), sy = (int)rintf(a.mapy[p] * 32.0f);
+    const int x0 = sx >> 5, y0 = sy >> 5;
+    const float ax = (float)(sx & 31) * (1.0f / 32.0f), ay = (float)(sy & 31) * (1.0f / 32.0f);
+    const float w0 = (1.0f - ay) * (1.0f - ax), w1 = (1.0f - ay) * ax, w2 = ay * (1.0f - ax), w3 = ay * ax;
+    auto tap = [&](int y, int x) { return (x >= 0 && y >= 0 && x < a.W && y < a.H) ? src[(size_t)y * a.W + x] : 0.0f; };
+    a.dst[i] = tap(y0, x0) * w0 + tap(y0, x0 + 1) * w1 + tap(y0 + 1, x0) * w2 + tap(y0 + 1, x0 + 1) * w3;
+}
+
+hipError_t launch_remap(const RemapArgs& a, hipStream_t s) {
+    const long total = (long)a.B * a.H * a.W;
+    hipLaunchKernelGGL(remap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
 // refineHeatMap (feature/src/PPGExtractor.cpp:540-578) on the tile grid of :243-256.
 // One work-group per tile (tiles are refine_sz^2, the last row/column of tiles absorbs the
 // remainder, so at most (2*sz-1)^2 pixels).  The row-major list of values > valid_thresh is rebuilt

@@ -508,3 +508,37 @@ def test_distinctive_descriptors_vs_oracle(pkg, orc):
     ref = [orc.distinctive_descriptor(desc[segs[p]:segs[p + 1]]) if segs[p + 1] > segs[p] else 0 for p in range(60)]
     assert best.tolist() == ref
     assert len(set(ref)) > 3
+
+
+@pytest.mark.parametrize("fisheye,D", [(0, (-0.28, 0.07, 2e-4, 2e-5)), (1, (-0.01, 0.004, -0.002, 0.0005))])
+def test_lens_distortion_path_vs_oracle(fisheye, D, pkg, orc, synth):
+    """D[0] != 0 (EuRoC-like pinhole coefficients, a Kannala-Brandt set): key points are undistorted, the refined heat
+    map goes through cv::remap before the line graph (PPGExtractor.cpp:221-223, 261-262).  Integer outputs exact
+    against the oracle when both start from the GPU's CNN tensors."""
+    H, W = 480, 640
+    cfg = pkg.default_config(W, H, max_num=500)
+    ocfg = orc.default_cfg(W, H, 500)
+    cfg.fisheye = ocfg.fisheye = fisheye
+    for k in range(4):
+        cfg.D[k] = ocfg.D[k] = D[k]
+    for k in range(9):
+        ocfg.K[k] = cfg.K[k]
+    ctx = pkg.Context(cfg)
+    try:
+        img = synth.make_frame(H, W, 91, 0, "sparse")
+        r = ctx.extract(img)
+        kp = orc.detect_keypoints(ocfg, ctx.read_tensor(pkg.T_SCORE))
+        assert r["n"] == kp["n"] > 50
+        assert np.array_equal(r["xy"], kp["xy"]) and np.array_equal(r["un"], kp["un"]) and np.array_equal(r["out"], kp["out"])
+        assert float(np.abs(r["un"] - r["xy"]).max()) > 1.0          # the lens model does move points
+        refined = orc.refine_heat(ocfg, ctx.read_tensor(pkg.T_HEAT))
+        assert np.array_equal(ctx.read_tensor(pkg.T_HEAT_REFINED), refined)
+        remapped = orc.remap_heat(ocfg, refined)
+        assert np.array_equal(ctx.read_tensor(pkg.T_HEAT_REMAPPED), remapped)
+        assert not np.array_equal(remapped, refined)
+        ln = orc.detect_lines(ocfg, remapped, kp["un"], kp["out"])
+        assert np.array_equal(r["edge_idx"], ln["edge_idx"]) and len(ln["edge_idx"]) > 10
+        assert np.array_equal(r["edge_score"], ln["edge_score"], equal_nan=True)
+        assert np.array_equal(r["conn_idx"], ln["conn_idx"]) and np.array_equal(r["coline_pairs"], ln["coline_pairs"])
+    finally:
+        ctx.close()

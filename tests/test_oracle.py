@@ -265,3 +265,32 @@ def test_distinctive_descriptor_known_answer(orc):
     assert orc.distinctive_descriptor(np.stack([e[0], e[1], e[2]])) == 0      # all medians sqrt(2) >= 1
     assert orc.distinctive_descriptor(e[:1]) == 0
     assert orc.distinctive_descriptor(np.stack([e[3], e[3]])) == 0            # N = 2: median = vDists[0] = 0 < 1
+
+
+def test_undistort_maps_and_remap(orc):
+    """PPGExtractor.cpp:65-71, 261-262 restated after OpenCV: without distortion the maps are the pixel grid and the
+    remap is the identity; with distortion the corners pull inwards/outwards and a linear ramp stays a ramp."""
+    cfg = orc.default_cfg(64, 48)
+    mx, my = orc.undistort_maps(cfg)
+    jj, ii = np.meshgrid(np.arange(64, dtype=np.float32), np.arange(48, dtype=np.float32))
+    assert np.abs(mx - jj).max() < 1e-4 and np.abs(my - ii).max() < 1e-4
+    rng = np.random.default_rng(3)
+    img = rng.random((48, 64), dtype=np.float32)
+    assert np.array_equal(orc.remap_heat(cfg, img), img)
+    cfg.D[0], cfg.D[1], cfg.D[2], cfg.D[3] = -0.28, 0.07, 2e-4, 2e-5
+    mx, my = orc.undistort_maps(cfg)
+    cx, cy = cfg.K[2], cfg.K[5]
+    # barrel distortion (k1 < 0): the source of a destination pixel lies closer to the centre
+    assert abs(mx[0, 0] - cx) < abs(0 - cx) and abs(my[0, 0] - cy) < abs(0 - cy)
+    assert abs(mx[24, 32] - 32) < 0.05 and abs(my[24, 32] - 24) < 0.05
+    ramp = (0.25 * jj + 0.5 * ii).astype(np.float32)
+    out = orc.remap_heat(cfg, ramp)
+    inside = (mx > 0) & (mx < 62) & (my > 0) & (my < 46)
+    want = 0.25 * np.round(mx * 32) / 32 + 0.5 * np.round(my * 32) / 32
+    assert np.abs(out - want)[inside].max() < 1e-4
+    # fisheye maps: radially symmetric about the principal point for fx = fy
+    cfg.fisheye = 1
+    cfg.K[0] = cfg.K[4] = 50.0
+    cfg.D[0], cfg.D[1], cfg.D[2], cfg.D[3] = 0.01, -0.002, 0.0, 0.0
+    mx, my = orc.undistort_maps(cfg)
+    assert abs((mx[24, 40] - 32) - (my[32, 32] - 24)) < 1e-4
