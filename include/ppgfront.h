@@ -140,6 +140,13 @@ int ppg_write_tensor(ppg_ctx* ctx, int which, int frame, const float* src, size_
  * d = 0..dim-1 as one fused-multiply-add chain per pair, then a correctly rounded square root. */
 int ppg_dist_matrix(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, int dim, float* D);
 
+/* DescriptorDistance for listed pairs only: row i of A against the rows cand_idx[cand_off[i] .. cand_off[i+1]-1] of B,
+ * D[k] for the k-th listed pair.  The inner arithmetic of every candidate-list matcher whose control flow stays on the
+ * host: Matcher::SearchByBoW (matching/src/Matcher.cpp:393-477, 663-754) and SearchForTriangulation (:767-885), where
+ * the lists are the shared DBoW3 FeatureVector nodes. */
+int ppg_dist_lists(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, int dim,
+                   const int32_t* cand_off, const int32_t* cand_idx, float* D);
+
 #define PPG_MATCH_PLAIN 0  /* rows independent: first argmin, best and second-best distance only      */
 #define PPG_MATCH_INIT 1   /* Matcher::SearchForInitialization claim semantics (Matcher.cpp:591-644)  */
 

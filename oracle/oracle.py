@@ -178,6 +178,66 @@ def search_for_initialization(cfg, nnratio, desc1, desc2, pos2, prev_matched, wi
     return cnt, m12, prev
 
 
+class FeatVec(C.Structure):
+    _fields_ = [("nn", C.c_int), ("node", C.c_void_p), ("off", C.c_void_p), ("idx", C.c_void_p)]
+
+
+def _featvec(fv):
+    """fv: list of (node id, [feature indices]) sorted by node id."""
+    node = np.array([n for n, _ in fv], np.uint32)
+    off = np.zeros(len(fv) + 1, np.int32)
+    for k, (_, ids) in enumerate(fv):
+        off[k + 1] = off[k] + len(ids)
+    idx = np.array([i for _, ids in fv for i in ids] or [0], np.uint32)
+    st = FeatVec()
+    st.nn = len(fv)
+    st.node, st.off, st.idx = node.ctypes.data, off.ctypes.data, idx.ctypes.data
+    return st, (node, off, idx)
+
+
+def search_by_bow_frame(cfg, nnratio, fvKF, fvF, descKF, mpKF, bad, descF):
+    a, ka = _featvec(fvKF)
+    b, kb = _featvec(fvF)
+    descKF = np.ascontiguousarray(descKF, np.float32)
+    descF = np.ascontiguousarray(descF, np.float32)
+    mpKF = np.ascontiguousarray(mpKF, np.int32)
+    bad = np.ascontiguousarray(bad, np.uint8)
+    out = np.full(descF.shape[0], -1, np.int32)
+    n = lib().ppgo_search_by_bow_frame(C.byref(cfg), C.c_float(nnratio), C.byref(a), C.byref(b), int(descKF.shape[0]), _p(descKF),
+                                       _p(mpKF), _p(bad), int(descF.shape[0]), _p(descF), _p(out))
+    return n, out
+
+
+def search_by_bow_keyframes(cfg, nnratio, fv1, fv2, desc1, mp1, desc2, mp2, bad):
+    a, ka = _featvec(fv1)
+    b, kb = _featvec(fv2)
+    desc1 = np.ascontiguousarray(desc1, np.float32)
+    desc2 = np.ascontiguousarray(desc2, np.float32)
+    mp1 = np.ascontiguousarray(mp1, np.int32)
+    mp2 = np.ascontiguousarray(mp2, np.int32)
+    bad = np.ascontiguousarray(bad, np.uint8)
+    out = np.full(desc1.shape[0], -1, np.int32)
+    n = lib().ppgo_search_by_bow_keyframes(C.byref(cfg), C.c_float(nnratio), C.byref(a), C.byref(b), int(desc1.shape[0]), _p(desc1),
+                                           _p(mp1), int(desc2.shape[0]), _p(desc2), _p(mp2), _p(bad), _p(out))
+    return n, out
+
+
+def search_for_triangulation(cfg, R1, t1, R2, t2, fv1, fv2, desc1, pos1, mp1, desc2, pos2, mp2):
+    a, ka = _featvec(fv1)
+    b, kb = _featvec(fv2)
+    p1, p2 = _pose(R1, t1), _pose(R2, t2)
+    desc1 = np.ascontiguousarray(desc1, np.float32)
+    desc2 = np.ascontiguousarray(desc2, np.float32)
+    pos1 = np.ascontiguousarray(pos1, np.float32)
+    pos2 = np.ascontiguousarray(pos2, np.float32)
+    mp1 = np.ascontiguousarray(mp1, np.int32)
+    mp2 = np.ascontiguousarray(mp2, np.int32)
+    pairs = np.full((max(desc1.shape[0], 1), 2), -1, np.int32)
+    n = lib().ppgo_search_for_triangulation(C.byref(cfg), C.byref(p1), C.byref(p2), C.byref(a), C.byref(b), int(desc1.shape[0]),
+                                            _p(desc1), _p(pos1), _p(mp1), int(desc2.shape[0]), _p(desc2), _p(pos2), _p(mp2), _p(pairs))
+    return n, pairs[:n].copy()
+
+
 def distinctive_descriptor(desc):
     desc = np.ascontiguousarray(desc, np.float32)
     L = lib()

@@ -726,6 +726,181 @@ int ppgo_fuse_match(const ppgo_cfg* c, const ppgo_pose* Tcw, const ppgo_mappoint
     return nFused;
 }
 
+namespace {
+// std::map<NodeId, vector<unsigned>>::lower_bound on the flattened form
+inline int fv_lower_bound(const ppgo_featvec* fv, uint32_t key) {
+    int k = 0;
+    while (k < fv->nn && fv->node[k] < key) k++;
+    return k;
+}
+}  // namespace
+
+int ppgo_search_by_bow_frame(const ppgo_cfg* c, float nnratio, const ppgo_featvec* fvKF, const ppgo_featvec* fvF,
+                             int nKF, const float* descKF, const int32_t* mpKF, const uint8_t* bad,
+                             int nF, const float* descF, int32_t* out) {
+    (void)nKF;
+    const int D = c->desc_dim;
+    const float TH_LOW = 0.7f;
+    for (int i = 0; i < nF; i++) out[i] = -1;
+    int nmatches = 0;
+    int KFit = 0, Fit = 0;
+    while (KFit != fvKF->nn && Fit != fvF->nn) {
+        if (fvKF->node[KFit] == fvF->node[Fit]) {
+            for (int iKF = fvKF->off[KFit]; iKF < fvKF->off[KFit + 1]; iKF++) {
+                const unsigned realIdxKF = fvKF->idx[iKF];
+                const int pMP = mpKF[realIdxKF];
+                if (pMP < 0) continue;
+                if (bad[pMP]) continue;
+                const float* dKF = descKF + (size_t)realIdxKF * D;
+                float bestDist1 = 1e6f, bestDist2 = 1e6f;
+                int bestIdxF = -1;
+                for (int iF = fvF->off[Fit]; iF < fvF->off[Fit + 1]; iF++) {
+                    const unsigned realIdxF = fvF->idx[iF];
+                    if (out[realIdxF] >= 0) continue;
+                    const float dist = ppgo_descriptor_distance(dKF, descF + (size_t)realIdxF * D, D);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if (bestDist1 < nnratio * bestDist2) { out[bestIdxF] = pMP; nmatches++; }
+                }
+            }
+            KFit++; Fit++;
+        } else if (fvKF->node[KFit] < fvF->node[Fit]) {
+            KFit = fv_lower_bound(fvKF, fvF->node[Fit]);
+        } else {
+            Fit = fv_lower_bound(fvF, fvKF->node[KFit]);
+        }
+    }
+    return nmatches;
+}
+
+int ppgo_search_by_bow_keyframes(const ppgo_cfg* c, float nnratio, const ppgo_featvec* fv1, const ppgo_featvec* fv2,
+                                 int n1, const float* desc1, const int32_t* mp1,
+                                 int n2, const float* desc2, const int32_t* mp2, const uint8_t* bad, int32_t* out) {
+    const int D = c->desc_dim;
+    const float TH_LOW = 0.7f;
+    for (int i = 0; i < n1; i++) out[i] = -1;
+    std::vector<bool> vbMatched2(std::max(n2, 1), false);
+    int nmatches = 0;
+    int f1it = 0, f2it = 0;
+    while (f1it != fv1->nn && f2it != fv2->nn) {
+        if (fv1->node[f1it] == fv2->node[f2it]) {
+            for (int i1 = fv1->off[f1it]; i1 < fv1->off[f1it + 1]; i1++) {
+                const size_t idx1 = fv1->idx[i1];
+                const int pMP1 = mp1[idx1];
+                if (pMP1 < 0) continue;
+                if (bad[pMP1]) continue;
+                const float* d1 = desc1 + idx1 * D;
+                float bestDist1 = 1e6f, bestDist2 = 1e6f;
+                int bestIdx2 = -1;
+                for (int i2 = fv2->off[f2it]; i2 < fv2->off[f2it + 1]; i2++) {
+                    const size_t idx2 = fv2->idx[i2];
+                    const int pMP2 = mp2[idx2];
+                    if (vbMatched2[idx2] || pMP2 < 0) continue;
+                    if (bad[pMP2]) continue;
+                    float dist = ppgo_descriptor_distance(d1, desc2 + idx2 * D, D);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (bestDist1 < nnratio * bestDist2) {
+                        out[idx1] = mp2[bestIdx2];
+                        vbMatched2[bestIdx2] = true;
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++; f2it++;
+        } else if (fv1->node[f1it] < fv2->node[f2it]) {
+            f1it = fv_lower_bound(fv1, fv2->node[f2it]);
+        } else {
+            f2it = fv_lower_bound(fv2, fv1->node[f1it]);
+        }
+    }
+    return nmatches;
+}
+
+int ppgo_search_for_triangulation(const ppgo_cfg* c, const ppgo_pose* T1w, const ppgo_pose* T2w,
+                                  const ppgo_featvec* fv1, const ppgo_featvec* fv2,
+                                  int n1, const float* desc1, const float* pos1, const int32_t* mp1,
+                                  int n2, const float* desc2, const float* pos2, const int32_t* mp2, int32_t* pairs) {
+    (void)n2;
+    const int D = c->desc_dim;
+    const float TH_LOW = 0.7f;
+    // epipole in KF2 (:779-782) and the relative pose T12 = T1w * Tw2 (:785-787)
+    float Cw[3], C2[3], ep[2];
+    cam_center(T1w, Cw);
+    se3_apply(T2w, Cw, C2);
+    pinhole_project(c, C2, ep);
+    float R12[9], t12[3];
+    for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 3; q++)
+            R12[3 * r + q] = T1w->R[3 * r] * T2w->R[3 * q] + T1w->R[3 * r + 1] * T2w->R[3 * q + 1] + T1w->R[3 * r + 2] * T2w->R[3 * q + 2];
+    for (int r = 0; r < 3; r++) t12[r] = T1w->t[r] - (R12[3 * r] * T2w->t[0] + R12[3 * r + 1] * T2w->t[1] + R12[3 * r + 2] * T2w->t[2]);
+    // F12 = K1^-T * t12x * R12 * K2^-1 (sensors/src/Pinhole.cpp:101-104); Eigen's inverse() is replaced by the closed
+    // form of the upper-triangular K, products left to right
+    const float fx = c->K[0], fy = c->K[4], cx = c->K[2], cy = c->K[5];
+    const float Ki[9] = {1.f / fx, 0.f, -cx / fx, 0.f, 1.f / fy, -cy / fy, 0.f, 0.f, 1.f};
+    const float tx[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};
+    auto mul = [](const float* X, const float* Y, float* Z) {
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) Z[3 * r + q] = X[3 * r] * Y[q] + X[3 * r + 1] * Y[3 + q] + X[3 * r + 2] * Y[6 + q];
+    };
+    float A[9], B[9], F12[9];
+    mul(tx, R12, A);
+    mul(A, Ki, B);
+    for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 3; q++) F12[3 * r + q] = Ki[r] * B[q] + Ki[3 + r] * B[3 + q] + Ki[6 + r] * B[6 + q];
+
+    int nmatches = 0;
+    std::vector<int> vMatches12(std::max(n1, 1), -1);
+    int f1it = 0, f2it = 0;
+    while (f1it != fv1->nn && f2it != fv2->nn) {
+        if (fv1->node[f1it] == fv2->node[f2it]) {
+            for (int i1 = fv1->off[f1it]; i1 < fv1->off[f1it + 1]; i1++) {
+                const size_t idx1 = fv1->idx[i1];
+                if (mp1[idx1] >= 0) continue;
+                const float* kp1 = pos1 + 2 * idx1;
+                const float* d1 = desc1 + idx1 * D;
+                float bestDist = TH_LOW;
+                int bestIdx2 = -1;
+                for (int i2 = fv2->off[f2it]; i2 < fv2->off[f2it + 1]; i2++) {
+                    size_t idx2 = fv2->idx[i2];
+                    if (mp2[idx2] >= 0) continue;  // vbMatched2 is never set (:794)
+                    const float dist = ppgo_descriptor_distance(d1, desc2 + idx2 * D, D);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const float* kp2 = pos2 + 2 * idx2;
+                    const float ex = ep[0] - kp2[0], ey = ep[1] - kp2[1];
+                    if (std::sqrt(ex * ex + ey * ey) < 10.0f) continue;
+                    // Pinhole::epipolarConstrain
+                    const float a = kp1[0] * F12[0] + kp1[1] * F12[3] + F12[6];
+                    const float b = kp1[0] * F12[1] + kp1[1] * F12[4] + F12[7];
+                    const float cc = kp1[0] * F12[2] + kp1[1] * F12[5] + F12[8];
+                    const float num = a * kp2[0] + b * kp2[1] + cc;
+                    const float den = a * a + b * b;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if ((double)dsqr < 3.84) { bestIdx2 = (int)idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) { vMatches12[idx1] = bestIdx2; nmatches++; }
+            }
+            f1it++; f2it++;
+        } else if (fv1->node[f1it] < fv2->node[f2it]) {
+            f1it = fv_lower_bound(fv1, fv2->node[f2it]);
+        } else {
+            f2it = fv_lower_bound(fv2, fv1->node[f1it]);
+        }
+    }
+    int k = 0;
+    for (int i = 0; i < n1; i++) {
+        if (vMatches12[i] < 0) continue;
+        pairs[2 * k] = i; pairs[2 * k + 1] = vMatches12[i];
+        k++;
+    }
+    return nmatches;
+}
+
 int ppgo_distinctive_descriptor(const float* desc, int n, int dim) {
     if (n <= 0) return 0;
     const size_t N = (size_t)n;

@@ -1316,6 +1316,38 @@ int ppg_features_in_area(const ppg_grid* g, float x, float y, float r, int32_t* 
     return cnt;
 }
 
+int ppg_dist_lists(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int dim, const int32_t* cand_off,
+                   const int32_t* cand_idx, float* D) {
+    if (!c) return PPG_EINVAL;
+    if (nA < 0 || nB < 0 || dim <= 0 || dim % 16 || (nA && (!A || !cand_off)))
+        return fail(c, PPG_EINVAL, "ppg_dist_lists: bad argument");
+    if (nA == 0) return PPG_OK;
+    if (cand_off[0] != 0) return fail(c, PPG_EINVAL, "cand_off[0] must be 0");
+    for (int i = 0; i < nA; i++)
+        if (cand_off[i + 1] < cand_off[i]) return fail(c, PPG_EINVAL, "cand_off must be non-decreasing");
+    const size_t nd = (size_t)cand_off[nA];
+    if (nd == 0) return PPG_OK;
+    if (!cand_idx || !D || !B) return fail(c, PPG_EINVAL, "ppg_dist_lists: null list, matrix or output");
+    for (size_t k = 0; k < nd; k++)
+        if (cand_idx[k] < 0 || cand_idx[k] >= nB) return fail(c, PPG_EINVAL, "cand_idx[%zu] out of range", k);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    hipStream_t s = c->post;
+    int rc = grow(c, c->mA, (size_t)nA * dim);
+    if (!rc) rc = grow(c, c->mB, (size_t)nB * dim);
+    if (!rc) rc = grow(c, c->mD, nd);
+    if (!rc) rc = grow(c, c->mOff, (size_t)nA + 1);
+    if (!rc) rc = grow(c, c->mIdx, nd);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->mA.p, A, sizeof(float) * nA * dim, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mB.p, B, sizeof(float) * nB * dim, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mOff.p, cand_off, sizeof(int32_t) * ((size_t)nA + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->mIdx.p, cand_idx, sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
+    HIPCHK(c, ppg::launch_dist_csr(c->mA.p, nA, c->mB.p, dim, c->mOff.p, c->mIdx.p, c->mD.p, s));
+    HIPCHK(c, hipMemcpyAsync(D, c->mD.p, sizeof(float) * nd, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return PPG_OK;
+}
+
 int ppg_distinctive_descriptors(ppg_ctx* c, const float* desc, const int32_t* seg_off, int P, int32_t* best) {
     if (!c) return PPG_EINVAL;
     if (P < 0 || (P && (!seg_off || !best))) return fail(c, PPG_EINVAL, "ppg_distinctive_descriptors: bad argument");

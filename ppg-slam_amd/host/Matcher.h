@@ -62,6 +62,19 @@ struct MapPointsView {
     int size() const { return (int)bad.size(); }
 };
 
+// DBoW3::FeatureVector (a std::map<NodeId, std::vector<unsigned>>) as the matchers walk it: entries sorted by node id.
+// With the shipped vocabularies (k = 9, L = 3) and the reference's levelsup = 4 (map/src/Frame.cpp:131) every feature
+// is filed under the root, i.e. one entry {0, [0 .. N-1]}: all_in_root().
+struct FeatureVectorView {
+    std::vector<std::pair<unsigned, std::vector<unsigned>>> nodes;
+    static FeatureVectorView all_in_root(int n) {
+        FeatureVectorView v;
+        v.nodes.emplace_back(0u, std::vector<unsigned>());
+        for (int i = 0; i < n; i++) v.nodes[0].second.push_back((unsigned)i);
+        return v;
+    }
+};
+
 // feature/src/MapPoint.cpp:22-29.  One pair per call launches a 1x1 distance matrix on the GPU; batch
 // pairs with ppg_dist_matrix wherever the caller has more than one.
 inline float DescriptorDistance(ppg_ctx* ctx, const DescMat& a, const DescMat& b) {
@@ -208,6 +221,103 @@ public:
         return nFused;
     }
 
+    // matching/src/Matcher.cpp:393-477.  KF.mvpMapPoints: GetMapPointMatches() as ids; bad[id] = isBad().
+    // vpMapPointMatches (size F.N) receives map-point ids.
+    int SearchByBoW(const FrameView& KF, const FeatureVectorView& fvKF, const FrameView& F, const FeatureVectorView& fvF,
+                    const std::vector<uint8_t>& bad, std::vector<int>& vpMapPointMatches) {
+        vpMapPointMatches.assign(F.mvKeysUn.size(), -1);
+        Lists L(*this, KF, fvKF, F, fvF, [&](unsigned idx) { const int id = mp(KF, idx); return id >= 0 && !bad[id]; });
+        int nmatches = 0;
+        for (size_t r = 0; r < L.rows.size(); r++) {
+            float bestDist1 = 1e6f, bestDist2 = 1e6f;
+            int bestIdxF = -1;
+            for (int k = L.off[r]; k < L.off[r + 1]; k++) {
+                const int realIdxF = L.idx[k];
+                if (vpMapPointMatches[realIdxF] >= 0) continue;
+                const float dist = L.D[k];
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 <= TH_LOW && bestDist1 < mfNNratio * bestDist2) {
+                vpMapPointMatches[bestIdxF] = mp(KF, L.rows[r]);
+                nmatches++;
+            }
+        }
+        return nmatches;
+    }
+
+    // matching/src/Matcher.cpp:663-754.  vpMatches12 (size KF1.N) receives the ids of KF2's map points.  (Frame and
+    // KeyFrame are one view type here, so the key-frame/key-frame overload carries a tag.)
+    struct BetweenKeyFrames {};
+    int SearchByBoW(const FrameView& KF1, const FeatureVectorView& fv1, const FrameView& KF2, const FeatureVectorView& fv2,
+                    const std::vector<uint8_t>& bad, std::vector<int>& vpMatches12, BetweenKeyFrames) {
+        vpMatches12.assign(KF1.mvKeysUn.size(), -1);
+        std::vector<uint8_t> vbMatched2(KF2.mvKeysUn.size(), 0);
+        Lists L(*this, KF1, fv1, KF2, fv2, [&](unsigned idx) { const int id = mp(KF1, idx); return id >= 0 && !bad[id]; });
+        int nmatches = 0;
+        for (size_t r = 0; r < L.rows.size(); r++) {
+            float bestDist1 = 1e6f, bestDist2 = 1e6f;
+            int bestIdx2 = -1;
+            for (int k = L.off[r]; k < L.off[r + 1]; k++) {
+                const int idx2 = L.idx[k];
+                const int id2 = mp(KF2, idx2);
+                if (vbMatched2[idx2] || id2 < 0) continue;
+                if (bad[id2]) continue;
+                const float dist = L.D[k];
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 < TH_LOW && bestDist1 < mfNNratio * bestDist2) {
+                vpMatches12[L.rows[r]] = mp(KF2, bestIdx2);
+                vbMatched2[bestIdx2] = 1;
+                nmatches++;
+            }
+        }
+        return nmatches;
+    }
+
+    // matching/src/Matcher.cpp:767-885 (pinhole epipolar test, sensors/src/Pinhole.cpp:98-115).  T1w, T2w: the key
+    // frames' poses.  Features that already hold a map point are skipped on both sides; vbMatched2 is never set by the
+    // reference, so one KF2 feature may pair with several KF1 features.
+    int SearchForTriangulation(const FrameView& KF1, const FeatureVectorView& fv1, const SE3f& T1w, const FrameView& KF2,
+                               const FeatureVectorView& fv2, const SE3f& T2w, std::vector<std::pair<size_t, size_t>>& vMatchedPairs) {
+        float Cw[3], C2[3], ep[2];
+        T1w.center(Cw);
+        T2w.apply(Cw, C2);
+        project(C2, ep);
+        // T12 = T1w * Tw2: R12 = R1 R2^T, t12 = t1 - R12 t2
+        float R12[9], t12[3];
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++)
+                R12[3 * r + q] = T1w.R[3 * r] * T2w.R[3 * q] + T1w.R[3 * r + 1] * T2w.R[3 * q + 1] + T1w.R[3 * r + 2] * T2w.R[3 * q + 2];
+        for (int r = 0; r < 3; r++) t12[r] = T1w.t[r] - (R12[3 * r] * T2w.t[0] + R12[3 * r + 1] * T2w.t[1] + R12[3 * r + 2] * T2w.t[2]);
+        float F12[9];
+        fundamental(R12, t12, F12);
+        std::vector<int> vMatches12(KF1.mvKeysUn.size(), -1);
+        Lists L(*this, KF1, fv1, KF2, fv2, [&](unsigned idx) { return mp(KF1, idx) < 0; });
+        int nmatches = 0;
+        for (size_t r = 0; r < L.rows.size(); r++) {
+            const KeyPointEx& kp1 = KF1.mvKeysUn[L.rows[r]];
+            float bestDist = TH_LOW;
+            int bestIdx2 = -1;
+            for (int k = L.off[r]; k < L.off[r + 1]; k++) {
+                const int idx2 = L.idx[k];
+                if (mp(KF2, idx2) >= 0) continue;
+                const float dist = L.D[k];
+                if (dist > TH_LOW || dist > bestDist) continue;
+                const KeyPointEx& kp2 = KF2.mvKeysUn[idx2];
+                const float ex = ep[0] - kp2.mPos[0], ey = ep[1] - kp2.mPos[1];
+                if (std::sqrt(ex * ex + ey * ey) < 10.0f) continue;
+                if (epipolarConstrain(kp1, kp2, F12)) { bestIdx2 = idx2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) { vMatches12[L.rows[r]] = bestIdx2; nmatches++; }
+        }
+        vMatchedPairs.clear();
+        for (size_t i = 0; i < vMatches12.size(); i++)
+            if (vMatches12[i] >= 0) vMatchedPairs.emplace_back(i, (size_t)vMatches12[i]);
+        return nmatches;
+    }
+
 public:
     static constexpr float TH_LOW = 0.7f;   // matching/src/Matcher.cpp:13
     static constexpr float TH_HIGH = 0.8f;  // matching/src/Matcher.cpp:12
@@ -216,6 +326,67 @@ public:
     float mfNNratio;
 
 private:
+    static int mp(const FrameView& F, unsigned idx) { return idx < F.mvpMapPoints.size() ? F.mvpMapPoints[idx] : -1; }
+    // The lock-step walk over two FeatureVectors (matching/src/Matcher.cpp:405-475): rows = the features of frame 1 that
+    // pass `take`, in walk order, each with the features of frame 2 filed under the same node; every listed
+    // DescriptorDistance comes from one GPU launch.
+    struct Lists {
+        std::vector<unsigned> rows;
+        std::vector<int32_t> off, idx;
+        std::vector<float> D;
+        template <typename Take>
+        Lists(Matcher& m, const FrameView& F1, const FeatureVectorView& fv1, const FrameView& F2, const FeatureVectorView& fv2, Take take) {
+            off.push_back(0);
+            size_t a = 0, b = 0;
+            while (a < fv1.nodes.size() && b < fv2.nodes.size()) {
+                if (fv1.nodes[a].first == fv2.nodes[b].first) {
+                    for (unsigned i1 : fv1.nodes[a].second) {
+                        if (!take(i1)) continue;
+                        rows.push_back(i1);
+                        for (unsigned i2 : fv2.nodes[b].second) idx.push_back((int32_t)i2);
+                        off.push_back((int32_t)idx.size());
+                    }
+                    a++; b++;
+                } else if (fv1.nodes[a].first < fv2.nodes[b].first) {
+                    while (a < fv1.nodes.size() && fv1.nodes[a].first < fv2.nodes[b].first) a++;  // lower_bound
+                } else {
+                    while (b < fv2.nodes.size() && fv2.nodes[b].first < fv1.nodes[a].first) b++;
+                }
+            }
+            D.assign(idx.size(), 0.f);
+            if (rows.empty() || idx.empty()) return;
+            DescMat d1((int)rows.size(), 256);
+            for (size_t r = 0; r < rows.size(); r++) std::memcpy(d1.ptr((int)r), F1.mDescriptors.ptr((int)rows[r]), sizeof(float) * 256);
+            m.check(ppg_dist_lists(m.mCtx, d1.data.data(), d1.rows, F2.mDescriptors.data.data(), F2.mDescriptors.rows, 256,
+                                   off.data(), idx.data(), D.data()));
+        }
+    };
+    // F12 = K^-T [t12]x R12 K^-1 (sensors/src/Pinhole.cpp:101-104), with the closed-form inverse of the upper-triangular K
+    void fundamental(const float* R12, const float* t12, float* F12) const {
+        const float fx = mpCamera->K[0], fy = mpCamera->K[4], cx = mpCamera->K[2], cy = mpCamera->K[5];
+        const float Ki[9] = {1.f / fx, 0.f, -cx / fx, 0.f, 1.f / fy, -cy / fy, 0.f, 0.f, 1.f};
+        const float tx[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};
+        float A[9], B[9];
+        mul3(tx, R12, A);
+        mul3(A, Ki, B);
+        // K^-T * B: (K^-T)[r][q] = Ki[q][r]
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) F12[3 * r + q] = Ki[r] * B[q] + Ki[3 + r] * B[3 + q] + Ki[6 + r] * B[6 + q];
+    }
+    static void mul3(const float* X, const float* Y, float* Z) {
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) Z[3 * r + q] = X[3 * r] * Y[q] + X[3 * r + 1] * Y[3 + q] + X[3 * r + 2] * Y[6 + q];
+    }
+    static bool epipolarConstrain(const KeyPointEx& kp1, const KeyPointEx& kp2, const float* F12) {
+        const float a = kp1.mPos[0] * F12[0] + kp1.mPos[1] * F12[3] + F12[6];
+        const float b = kp1.mPos[0] * F12[1] + kp1.mPos[1] * F12[4] + F12[7];
+        const float c = kp1.mPos[0] * F12[2] + kp1.mPos[1] * F12[5] + F12[8];
+        const float num = a * kp2.mPos[0] + b * kp2.mPos[1] + c;
+        const float den = a * a + b * b;
+        if (den == 0) return false;
+        const float dsqr = num * num / den;
+        return (double)dsqr < 3.84;
+    }
     // Frame::AssignFeaturesToGrid over mvKeysUn (map/src/Frame.cpp:138-156), freed with the scope
     struct Grid {
         ppg_grid* g = nullptr;

@@ -72,6 +72,45 @@ static int projection_demo(Matcher& matcher, const CameraModel& cam, FrameView F
     for (size_t i = 0; i < fuse_pts.size(); i += 23) fuse_pts[i] = -1;
     const int n3 = matcher.Fuse(F[1], Tcw, map, fuse_pts, in_kf, 3.f, true, best_a);
     const int n4 = matcher.Fuse(F[1], Tcw, map, fuse_pts, in_kf, 4.f, false, best_b);
+    // ---- FeatureVector matchers: features filed by a 160-px position bucket, some nodes missing on either side ----
+    auto file_features = [&](const FrameView& F, int drop_mod, int drop_rem) {
+        std::vector<std::vector<unsigned>> bucket(64);
+        for (size_t i = 0; i < F.mvKeysUn.size(); i++) {
+            const int node = 1 + (int)(F.mvKeysUn[i].mPos[1] / 160.f) * 4 + (int)(F.mvKeysUn[i].mPos[0] / 160.f);
+            if (node >= 0 && node < 64) bucket[node].push_back((unsigned)i);
+        }
+        FeatureVectorView fv;
+        for (unsigned n = 0; n < 64; n++)
+            if (!bucket[n].empty() && (int)(n % drop_mod) != drop_rem) fv.nodes.emplace_back(n, bucket[n]);
+        return fv;
+    };
+    auto flatten = [](const FeatureVectorView& fv, std::vector<int>& node, std::vector<int>& off, std::vector<int>& idx) {
+        off.push_back(0);
+        for (auto& e : fv.nodes) {
+            node.push_back((int)e.first);
+            for (unsigned i : e.second) idx.push_back((int)i);
+            off.push_back((int)idx.size());
+        }
+    };
+    const FeatureVectorView fvA = file_features(F[0], 5, 2), fvB = file_features(F[1], 7, 3);
+    FrameView A = F[0], B = F[1];
+    for (int j = 0; j < nb; j++) B.mvpMapPoints[j] = j % 3 ? (j * 3) % std::max(na, 1) : -1;
+    std::vector<int> bow_f, bow_kk;
+    Matcher loose(matcher.mCtx, &cam, 0.9f);
+    const int n5 = loose.SearchByBoW(A, fvA, B, fvB, map.bad, bow_f);
+    const int n6 = loose.SearchByBoW(A, fvA, B, fvB, map.bad, bow_kk, Matcher::BetweenKeyFrames());
+    FrameView A2 = F[0], B2 = F[1];
+    for (int i = 0; i < na; i++) A2.mvpMapPoints[i] = i % 2 ? i : -1;
+    for (int j = 0; j < nb; j++) B2.mvpMapPoints[j] = j % 4 == 1 ? 0 : -1;
+    std::vector<std::pair<size_t, size_t>> tri;
+    SE3f T1w;
+    const int n7 = loose.SearchForTriangulation(A2, fvA, T1w, B2, fvB, Tcw, tri);
+    std::vector<int> tri_flat;
+    for (auto& pr : tri) { tri_flat.push_back((int)pr.first); tri_flat.push_back((int)pr.second); }
+    // the root-only FeatureVector of the shipped vocabularies
+    std::vector<int> bow_root;
+    const int n8 = loose.SearchByBoW(A, FeatureVectorView::all_in_root(na), B, FeatureVectorView::all_in_root(nb), map.bad, bow_root);
+
     FILE* f = fopen(out_path, "wb");
     if (!f) return 2;
     std::vector<float> pose(Tcw.R, Tcw.R + 9), posb, camk(cam.K, cam.K + 9);
@@ -85,6 +124,14 @@ static int projection_demo(Matcher& matcher, const CameraModel& cam, FrameView F
     dump(f, cur_before); dump(f, cur.mvpMapPoints);
     dump(f, points); dump(f, matched_before); dump(f, matched);
     dump(f, fuse_pts); dump(f, in_kf); dump(f, best_a); dump(f, best_b);
+    std::vector<int> nodeA, offA, idxA, nodeB, offB, idxB, counts2 = {n5, n6, n7, n8};
+    flatten(fvA, nodeA, offA, idxA);
+    flatten(fvB, nodeB, offB, idxB);
+    std::vector<float> posa;
+    for (auto& kp : F[0].mvKeysUn) { posa.push_back(kp.mPos[0]); posa.push_back(kp.mPos[1]); }
+    dump(f, counts2); dump(f, nodeA); dump(f, offA); dump(f, idxA); dump(f, nodeB); dump(f, offB); dump(f, idxB);
+    dump(f, posa); dump(f, A.mvpMapPoints); dump(f, B.mvpMapPoints); dump(f, bow_f); dump(f, bow_kk);
+    dump(f, A2.mvpMapPoints); dump(f, B2.mvpMapPoints); dump(f, tri_flat); dump(f, bow_root);
     fclose(f);
     return 0;
 }

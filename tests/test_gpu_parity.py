@@ -438,7 +438,10 @@ def _read_dump(path):
     dtypes = [np.int32, np.float32, np.float32,                                       # counts, K, pose
               np.float32, np.float32, np.float32, np.float32, np.float32, np.uint8, np.int32,   # map
               np.int32, np.uint8, np.float32, np.float32,                               # last_mp, outlier, pos B, desc B
-              np.int32, np.int32, np.int32, np.int32, np.int32, np.int32, np.uint8, np.int32, np.int32]
+              np.int32, np.int32, np.int32, np.int32, np.int32, np.int32, np.uint8, np.int32, np.int32,
+              np.int32, np.int32, np.int32, np.int32, np.int32, np.int32, np.int32,    # counts2, FeatureVectors A and B
+              np.float32, np.int32, np.int32, np.int32, np.int32,                      # pos A, mp A, mp B, bow results
+              np.int32, np.int32, np.int32, np.int32]                                  # triangulation inputs / pairs, root
     out = []
     for dt in dtypes:
         (n,) = struct.unpack_from("<i", data, ofs)
@@ -470,7 +473,8 @@ def test_host_mirror_projection_matchers_vs_oracle(pkg, orc, synth, tmp_path):
                          capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stderr
     (counts, K, pose, pos, normal, dmin, dmax, desc, bad, nobs, last_mp, outlier, posb, descb, cur_before, cur_after,
-     points, matched_before, matched_after, fuse_pts, in_kf, best_a, best_b) = _read_dump(dump)
+     points, matched_before, matched_after, fuse_pts, in_kf, best_a, best_b,
+     counts2, nodeA, offA, idxA, nodeB, offB, idxB, posa, mpA, mpB, bow_f, bow_kk, mpA2, mpB2, tri, bow_root) = _read_dump(dump)
     n1, n2, n3, n4, Wd, Hd = [int(v) for v in counts]
     assert (Wd, Hd) == (W, H) and len(bad) > 100 and len(posb) // 2 > 100
     cfg = orc.default_cfg(W, H)
@@ -489,6 +493,22 @@ def test_host_mirror_projection_matchers_vs_oracle(pkg, orc, synth, tmp_path):
     assert o3 == n3 and o3 > 5 and np.array_equal(ba, best_a)
     o4, bb = orc.fuse_match(cfg, R, t, mp, fuse_pts, in_kf, posb, descb, 4.0, False)
     assert o4 == n4 and o4 >= o3 and np.array_equal(bb, best_b)
+    # ---- the FeatureVector matchers (desc of frame A = the map descriptors, by construction of the demo map) ----
+    n5, n6, n7, n8 = [int(v) for v in counts2]
+    fvA = [(int(nodeA[k]), idxA[offA[k]:offA[k + 1]].tolist()) for k in range(len(nodeA))]
+    fvB = [(int(nodeB[k]), idxB[offB[k]:offB[k + 1]].tolist()) for k in range(len(nodeB))]
+    assert len(fvA) >= 3 and len(fvB) >= 3 and [n for n, _ in fvA] != [n for n, _ in fvB]
+    desca = desc.reshape(-1, 256)
+    o5, out = orc.search_by_bow_frame(cfg, 0.9, fvA, fvB, desca, mpA, bad, descb)
+    assert o5 == n5 and o5 > 10 and np.array_equal(out, bow_f)
+    o6, out = orc.search_by_bow_keyframes(cfg, 0.9, fvA, fvB, desca, mpA, descb, mpB, bad)
+    assert o6 == n6 and o6 > 5 and np.array_equal(out, bow_kk)
+    o7, pairs = orc.search_for_triangulation(cfg, np.eye(3), np.zeros(3), R, t, fvA, fvB, desca, posa.reshape(-1, 2), mpA2,
+                                             descb, posb, mpB2)
+    assert o7 == n7 and o7 > 5 and np.array_equal(pairs.reshape(-1), tri)
+    root = lambda n: [(0, list(range(n)))]
+    o8, out = orc.search_by_bow_frame(cfg, 0.9, root(len(desca)), root(len(descb)), desca, mpA, bad, descb)
+    assert o8 == n8 and o8 >= o5 and np.array_equal(out, bow_root)
 
 
 def test_distinctive_descriptors_vs_oracle(pkg, orc):

@@ -294,3 +294,45 @@ def test_undistort_maps_and_remap(orc):
     cfg.D[0], cfg.D[1], cfg.D[2], cfg.D[3] = 0.01, -0.002, 0.0, 0.0
     mx, my = orc.undistort_maps(cfg)
     assert abs((mx[24, 40] - 32) - (my[32, 32] - 24)) < 1e-4
+
+
+def test_feature_vector_matchers_small(orc):
+    """Matcher.cpp:393-477 / 663-754 / 767-885 on two nodes: only features of the same node are compared (lock-step
+    walk with lower_bound), a matched frame slot is not offered again, the ratio test is strict."""
+    cfg = _tiny_cfg(orc)
+    e = np.eye(256, dtype=np.float32)
+    d1 = np.stack([e[0], 0.8 * e[0] + 0.6 * e[1], e[2], e[3]])       # KF features 0..3
+    d2 = np.stack([e[0], e[2], 0.6 * e[0] + 0.8 * e[1], e[3]])       # F features 0..3
+    mp1 = np.array([0, 1, 2, -1], np.int32)
+    bad = np.zeros(3, np.uint8)
+    fv1 = [(1, [0, 1]), (4, [2]), (9, [3])]
+    fv2 = [(1, [0, 2]), (3, [3]), (4, [1])]
+    n, out = orc.search_by_bow_frame(cfg, 0.9, fv1, fv2, d1, mp1, bad, d2)
+    # KF0 -> F0 (0 < 0.9 * 0.894); KF1: F0 taken, F2 at 0.283 with no second (1e6) -> F2; KF2 -> F1 in node 4; KF3 has no MP
+    assert n == 3 and out.tolist() == [0, 2, 1, -1]                  # indexed by frame slot: slot 1 <- point 2, slot 2 <- point 1
+    n, out = orc.search_by_bow_frame(cfg, 0.9, [(2, [0, 1, 2, 3])], fv2, d1, mp1, bad, d2)
+    assert n == 0 and out.tolist() == [-1, -1, -1, -1]               # no common node
+    bad[1] = 1
+    n, out = orc.search_by_bow_frame(cfg, 0.9, fv1, fv2, d1, mp1, bad, d2)
+    assert n == 2 and out.tolist() == [0, 2, -1, -1]                 # slot 2 stays free: its only suitor is bad
+    # key frame / key frame: KF2 slots need a good map point of their own; results are KF2's map points
+    bad[:] = 0
+    mp2 = np.array([2, -1, 0, 1], np.int32)
+    n, out = orc.search_by_bow_keyframes(cfg, 0.9, fv1, fv2, d1, mp1, d2, mp2, bad)
+    assert n == 2 and out.tolist() == [2, 0, -1, -1]                 # KF1 feature 2: its only candidate has no map point
+    # triangulation: only features WITHOUT map points pair up; a distant epipole and a pure x translation
+    pos1 = np.array([[10, 10], [20, 12], [30, 30], [40, 20]], np.float32)
+    pos2 = pos1 + np.array([2.0, 0.0], np.float32)
+    d = np.stack([e[0], e[1], e[2], e[3]])
+    none = np.full(4, -1, np.int32)
+    root = [(0, [0, 1, 2, 3])]
+    R, t2 = np.eye(3, dtype=np.float32), np.array([0.05, 0.0, 0.0], np.float32)
+    n, pairs = orc.search_for_triangulation(cfg, R, np.zeros(3, np.float32), R, t2, root, root, d, pos1, none, d, pos2, none)
+    assert n == 4 and pairs.tolist() == [[0, 0], [1, 1], [2, 2], [3, 3]]
+    n, pairs = orc.search_for_triangulation(cfg, R, np.zeros(3, np.float32), R, t2, root, root, d, pos1,
+                                            np.array([-1, 5, -1, -1], np.int32), d, pos2, np.array([-1, -1, 7, -1], np.int32))
+    assert n == 2 and pairs.tolist() == [[0, 0], [3, 3]]
+    # off the epipolar line (a vertical offset of 5 px with a horizontal baseline): rejected
+    pos2b = pos1 + np.array([2.0, 5.0], np.float32)
+    n, pairs = orc.search_for_triangulation(cfg, R, np.zeros(3, np.float32), R, t2, root, root, d, pos1, none, d, pos2b, none)
+    assert n == 0
