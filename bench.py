@@ -128,11 +128,14 @@ def main():
 
     stats = {"kp": 0, "edges": 0, "matches": 0}
 
+    do_match = [True]
+
     def submit(k):
+        mp = do_match[0] and k > 0
         if args.host_input:
-            ctx.submit_batch(list(host[k % T]), match_prev=k > 0, nnratio=0.9)
+            ctx.submit_batch(list(host[k % T]), match_prev=mp, nnratio=0.9)
         else:
-            ctx.submit_batch_device(frames[k % T].data_ptr(), B, match_prev=k > 0, nnratio=0.9)
+            ctx.submit_batch_device(frames[k % T].data_ptr(), B, match_prev=mp, nnratio=0.9)
 
     def wait(k):
         outs, cnts, _, n = ctx.wait_batch(to_dict=False, want_matches=True)
@@ -186,6 +189,16 @@ def main():
     prof_all = ctx.profile_read()
     fl_all = ctx.last_profile_flops
     ctx.profile(False)
+    # Third pass, extract only (no match against the previous frame): the second of the two rates the metric names.
+    do_match[0] = False
+    base = preroll + args.warmup + 1 + args.steps + nb
+    run(base, 4)
+    barrier()
+    t1 = time.perf_counter()
+    ne = max(nb, min(args.steps, 30))
+    run(base + 4, ne)
+    barrier()
+    extract_only_fps = B * ne * world / (time.perf_counter() - t1)
 
     if rank == 0:
         dom_ms, dom_launches = prof["conv1a"]
@@ -222,6 +235,7 @@ def main():
                                                     "ms_per_step": round(o_ms / nb, 4)},
                          "all_convolutions_achieved": round(all_conv_tf, 2)},
             "device_ms_per_step": {k: round(v[0] / nb, 4) for k, v in prof_all.items()},
+            "extract_only_frames_per_s": round(extract_only_fps, 1),
             "device_ms_note": f"from a second pass of {nb} steps with events around every kernel class (not the timed region)",
         }
         tr = os.path.join(ROOT, "profiles", "traffic.json")

@@ -269,14 +269,16 @@ void* ppg_stream(ppg_ctx* ctx);
 #define PPG_PROF_CONV3X3 0     /* conv_mfma_kernel<3,2,8,false>: the 3x3 convolutions with >= 64 couts after conv1b */
 #define PPG_PROF_CONV_OTHER 1  /* the 1x1 convolutions and the 16-cout 3x3 one */
 #define PPG_PROF_CONV1A 2      /* conv_mfma_kernel<3,2,8,true>: conv1a fused into conv1b (or conv1a_kernel alone) */
-#define PPG_PROF_POST 3        /* score map, NMS, heat map, refine, line candidates, descriptors */
+#define PPG_PROF_POST 3        /* detectKeyPoint: score map, NMS, ranking, undistortion */
 #define PPG_PROF_MATCH 4
 #define PPG_PROF_HOST_WAIT 5   /* host wall time blocked in hipStreamSynchronize inside ppg_collect */
 #define PPG_PROF_HOST_TAIL 6   /* host wall time of the order-dependent line-graph tail */
 #define PPG_PROF_HOST_SUBMIT 7 /* host wall time inside ppg_submit_batch* (launch + copy enqueue) */
 #define PPG_PROF_HOST_FINISH 8 /* host wall time inside ppg_wait_batch */
 #define PPG_PROF_HOST_TAIL_FRAMES 9 /* sum over frames of the per-frame tail time (launches = frames) */
-#define PPG_PROF_N 10
+#define PPG_PROF_LINES 10      /* detectLines on the device: heat tail, refine, remap, pair probe, scores */
+#define PPG_PROF_DESC 11       /* genPointDescriptor */
+#define PPG_PROF_N 12
 int ppg_profile(ppg_ctx* ctx, int enable);
 int ppg_profile_read(ppg_ctx* ctx, double* ms, long long* launches);
 /* Algorithmic FLOPs (2 x MACs of the layers' shapes) enqueued per class since ppg_profile(ctx, 1); conv classes only. */

@@ -284,13 +284,14 @@ class Context:
         self._chk(self.L.ppg_profile(C.c_void_p(self.h), 2 if enable == 2 else (1 if enable else 0)))
 
     def profile_read(self):
-        ms = (C.c_double * 10)()
-        launches = (C.c_longlong * 10)()
+        ms = (C.c_double * 12)()
+        launches = (C.c_longlong * 12)()
         self._chk(self.L.ppg_profile_read(C.c_void_p(self.h), ms, launches))
-        fl = (C.c_double * 10)()
+        fl = (C.c_double * 12)()
         self._chk(self.L.ppg_profile_flops(C.c_void_p(self.h), fl))
         self.last_profile_flops = {k: fl[i] for i, k in enumerate(("conv3x3", "conv_other", "conv1a"))}
-        names = ("conv3x3", "conv_other", "conv1a", "post", "match", "host_wait", "host_tail", "host_submit", "host_finish", "host_tail_frames")
+        names = ("conv3x3", "conv_other", "conv1a", "keypoints", "match", "host_wait", "host_tail", "host_submit", "host_finish", "host_tail_frames",
+                 "lines", "descriptors")
         return {k: (ms[i], launches[i]) for i, k in enumerate(names)}
 
     def distinctive_descriptors(self, desc, seg_off):

@@ -865,7 +865,7 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
-    ProfScope ps(c, PPG_PROF_POST, c->post);
+    ProfScope ps(c, PPG_PROF_LINES, c->post);
     ppg::HeatArgs ha = heat_args(c, n);
     // last layer of EdgeHeatmap (1x1 conv 4->2, heatmap_decoder.py:22) fused with the 2-way softmax of :242
     if (!c->skip_heat) HIPCHK(c, ppg::launch_heat_tail(ha, c->post));
@@ -890,7 +890,7 @@ int ppg_gen_descriptors(ppg_ctx* c, int n) {
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
-    ProfScope ps(c, PPG_PROF_POST, c->post);
+    ProfScope ps(c, PPG_PROF_DESC, c->post);
     ppg::DescArgs a;
     a.descmap = c->descmap; a.kp_xy = c->kp_xy; a.counters = c->counters; a.desc = c->desc;
     a.B = n; a.H = c->H; a.W = c->W; a.max_num = c->maxn;

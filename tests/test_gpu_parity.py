@@ -121,7 +121,7 @@ def test_ragged_sizes_vs_oracle(pkg, orc, onet, synth):
 
 
 def test_full_size_postprocessing_exact_on_gpu_tensors(pkg, orc, synth):
-    """BASELINE sizes: every integer output equals the oracle's when both start from the GPU's CNN tensors."""
+    """The benchmark image sizes: every integer output equals the oracle's when both start from the GPU's CNN tensors."""
     for (H, W, seed, kind, maxnum) in ((480, 640, 31, "sparse", 500), (480, 640, 32, "dense", 1024), (512, 512, 33, "dense", 1024),
                                        (1024, 1024, 34, "sparse", 1024)):
         ctx = get_ctx(pkg, W, H, maxnum)
