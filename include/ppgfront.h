@@ -193,6 +193,15 @@ int ppg_features_in_area(const ppg_grid* g, float x, float y, float r, int32_t* 
 /* GeometricCamera::IsInImage (sensors/src/GeometricCamera.cpp:21-24) with the bounds the grid was built with. */
 int ppg_grid_is_in_image(const ppg_grid* g, float x, float y);
 
+/* Frame::CheckInFrustum (map/src/Frame.cpp:223-260) for m map points at once (host arithmetic: it prepares the
+ * mTrackProjX/Y, mTrackViewCos, mbTrackInView inputs of ppg_extend_map_matches).  pose = camera-from-world rotation
+ * (row-major 3x3) followed by the translation, 12 floats; "R * P + t", ".norm()" and ".dot()" are evaluated left to
+ * right in float.  Outputs per point: in_view (0/1), proj (2 floats, -1 when not in view), depth and view_cos
+ * (-1 / unchanged semantics of the reference: depth -1 when not in view; view_cos written only when in view). */
+int ppg_check_in_frustum(const ppg_grid* bounds, const float* K9, const float* pose12, int m,
+                         const float* pos, const float* normal, const float* min_dist, const float* max_dist,
+                         float viewing_cos_limit, uint8_t* in_view, float* proj, float* depth, float* view_cos);
+
 /* The windowed projection matchers: Matcher::SearchByProjection(Frame&, const Frame&, th) (matching/src/Matcher.cpp:31-87),
  * SearchByProjection(Frame&, vector<MapPoint*>&, th) (:89-189), SearchByProjection(KeyFrame*, Sim3f&, ...) (:479-568),
  * Fuse(KeyFrame*, vector<MapPoint*>&, th) (:897-1036) and Fuse(KeyFrame*, Sim3f&, ...) (:1038-1135) share one inner

@@ -276,6 +276,18 @@ def _pose(R, t):
     return p
 
 
+def check_in_frustum(cfg, R, t, mp, limit):
+    st, keep = _mappoints(mp)
+    pose = _pose(R, t)
+    m = st.m
+    in_view = np.zeros(m, np.uint8)
+    proj = np.zeros((m, 2), np.float32)
+    depth = np.zeros(m, np.float32)
+    vc = np.full(m, np.nan, np.float32)
+    lib().ppgo_check_in_frustum(C.byref(cfg), C.byref(pose), C.byref(st), C.c_float(limit), _p(in_view), _p(proj), _p(depth), _p(vc))
+    return in_view, proj, depth, vc
+
+
 def search_by_projection_frames(cfg, R, t, mp, last_mp, last_outlier, cur_pos, cur_desc, cur_mp, th):
     st, keep = _mappoints(mp)
     pose = _pose(R, t)

@@ -620,6 +620,37 @@ inline bool project_gates(const ppgo_cfg* c, const ppgo_grid* g, const ppgo_pose
 }
 }  // namespace
 
+void ppgo_check_in_frustum(const ppgo_cfg* c, const ppgo_pose* Tcw, const ppgo_mappoints* mp, float viewingCosLimit,
+                           uint8_t* in_view, float* proj, float* depth, float* view_cos) {
+    ppgo_grid* g = ppgo_grid_build(c, 0, nullptr);  // image bounds only
+    float mOw[3];
+    cam_center(Tcw, mOw);
+    for (int i = 0; i < mp->m; i++) {
+        in_view[i] = 0;          // mbTrackInView = false
+        proj[2 * i] = -1;        // mTrackProjX
+        proj[2 * i + 1] = -1;    // mTrackProjY
+        depth[i] = -1;           // mTrackDepth
+        const float* P = mp->pos + 3 * (size_t)i;
+        float Pc[3], uv[2];
+        se3_apply(Tcw, P, Pc);
+        if (Pc[2] < 0.0f) continue;
+        pinhole_project(c, Pc, uv);
+        if (!in_image(g, uv[0], uv[1])) continue;
+        const float PO[3] = {P[0] - mOw[0], P[1] - mOw[1], P[2] - mOw[2]};
+        const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+        if (dist < mp->min_dist[i] || dist > mp->max_dist[i]) continue;
+        const float* Pn = mp->normal + 3 * (size_t)i;
+        const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+        if (viewCos < viewingCosLimit) continue;
+        in_view[i] = 1;
+        proj[2 * i] = uv[0];
+        proj[2 * i + 1] = uv[1];
+        depth[i] = dist;
+        view_cos[i] = viewCos;
+    }
+    ppgo_grid_free(g);
+}
+
 int ppgo_search_by_projection_frames(const ppgo_cfg* c, const ppgo_pose* Tcw, const ppgo_mappoints* mp,
                                      int nl, const int32_t* last_mp, const uint8_t* last_outlier,
                                      int nc, const float* cur_pos, const float* cur_desc, int32_t* cur_mp, float th) {

@@ -294,6 +294,27 @@ class Context:
                  "lines", "descriptors")
         return {k: (ms[i], launches[i]) for i, k in enumerate(names)}
 
+    def check_in_frustum(self, pose12, pos, normal, min_dist, max_dist, limit):
+        """Frame::CheckInFrustum for m points (host arithmetic); returns in_view, proj, depth, view_cos (nan when unset)."""
+        pos = np.ascontiguousarray(pos, np.float32)
+        normal = np.ascontiguousarray(normal, np.float32)
+        dmin = np.ascontiguousarray(min_dist, np.float32)
+        dmax = np.ascontiguousarray(max_dist, np.float32)
+        pose = np.ascontiguousarray(pose12, np.float32)
+        K = np.array([self.cfg.K[k] for k in range(9)], np.float32)
+        m = pos.shape[0]
+        g = self.L.ppg_grid_build(C.byref(self.cfg), None, 0)
+        in_view = np.zeros(m, np.uint8)
+        proj = np.zeros((m, 2), np.float32)
+        depth = np.zeros(m, np.float32)
+        vc = np.full(m, np.nan, np.float32)
+        self.L.ppg_check_in_frustum.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4
+        rc = self.L.ppg_check_in_frustum(C.c_void_p(g), _p(K), _p(pose), m, _p(pos), _p(normal), _p(dmin), _p(dmax),
+                                         C.c_float(limit), _p(in_view), _p(proj), _p(depth), _p(vc))
+        self.L.ppg_grid_free(C.c_void_p(g))
+        self._chk(rc)
+        return in_view, proj, depth, vc
+
     def distinctive_descriptors(self, desc, seg_off):
         """MapPoint::ComputeDistinctiveDescriptors for every segment of `desc` rows; returns BestIdx per segment."""
         desc = np.ascontiguousarray(desc, np.float32)

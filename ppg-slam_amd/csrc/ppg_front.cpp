@@ -1404,6 +1404,36 @@ int ppg_grid_is_in_image(const ppg_grid* g, float x, float y) {
     return x >= (float)g->minX && x < (float)g->maxX && y >= (float)g->minY && y < (float)g->maxY;
 }
 
+int ppg_check_in_frustum(const ppg_grid* g, const float* K, const float* T, int m, const float* pos, const float* normal,
+                         const float* min_dist, const float* max_dist, float limit, uint8_t* in_view, float* proj,
+                         float* depth, float* view_cos) {
+    if (!g || !K || !T || m < 0 || (m && (!pos || !normal || !min_dist || !max_dist || !in_view || !proj))) return PPG_EINVAL;
+    float Ow[3];  // camera centre: -R^T t
+    for (int r = 0; r < 3; r++) Ow[r] = -(T[r] * T[9] + T[3 + r] * T[10] + T[6 + r] * T[11]);
+    for (int i = 0; i < m; i++) {
+        in_view[i] = 0;
+        proj[2 * i] = -1.f; proj[2 * i + 1] = -1.f;
+        if (depth) depth[i] = -1.f;
+        const float* P = pos + 3 * (size_t)i;
+        float Pc[3];
+        for (int r = 0; r < 3; r++) Pc[r] = T[3 * r] * P[0] + T[3 * r + 1] * P[1] + T[3 * r + 2] * P[2] + T[9 + r];
+        if (Pc[2] < 0.0f) continue;
+        const float u = K[0] * Pc[0] / Pc[2] + K[2], v = K[4] * Pc[1] / Pc[2] + K[5];  // Pinhole::project
+        if (!ppg_grid_is_in_image(g, u, v)) continue;
+        const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+        const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+        if (dist < min_dist[i] || dist > max_dist[i]) continue;
+        const float* Pn = normal + 3 * (size_t)i;
+        const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+        if (viewCos < limit) continue;
+        in_view[i] = 1;
+        proj[2 * i] = u; proj[2 * i + 1] = v;
+        if (depth) depth[i] = dist;
+        if (view_cos) view_cos[i] = viewCos;
+    }
+    return PPG_OK;
+}
+
 int ppg_match_projected(ppg_ctx* c, const ppg_proj_args* a, int32_t* best_idx, float* best_dist, int* n_matches) {
     if (!c) return PPG_EINVAL;
     if (!a || !a->grid || a->n1 < 0 || a->n2 < 0 || a->n2 != a->grid->n || (a->n1 && (!a->desc1 || !a->uv || !a->radius || !best_idx)) ||

@@ -82,3 +82,44 @@ def test_host_mirror_compiles():
     demo = os.path.join(ROOT, "ppg-slam_amd", "host", "shim_demo")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "ppg-slam_amd", "csrc"), "demo"])
     assert os.path.exists(demo)
+
+
+def test_check_in_frustum_host_logic_vs_oracle(pkg, orc):
+    """Frame::CheckInFrustum (map/src/Frame.cpp:223-260), batched: host arithmetic of the library against the oracle."""
+    W, H = 640, 480
+    cfg = pkg.default_config(W, H)
+    ocfg = orc.default_cfg(W, H)
+    for k in range(9):
+        ocfg.K[k] = cfg.K[k]
+    rng = np.random.default_rng(11)
+    m = 400
+    pos = np.stack([rng.uniform(-3, 3, m), rng.uniform(-2, 2, m), rng.uniform(-1, 6, m)], 1).astype(np.float32)
+    nrm = pos + rng.normal(0, 0.8, (m, 3)).astype(np.float32)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    d = np.linalg.norm(pos, axis=1).astype(np.float32)
+    dmin = (d * rng.uniform(0.3, 1.1, m)).astype(np.float32)
+    dmax = (d * rng.uniform(0.9, 2.0, m)).astype(np.float32)
+    th = 0.1
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+    t = np.array([0.05, -0.02, 0.1], np.float32)
+    L = pkg.lib()
+    g = L.ppg_grid_build(C.byref(cfg), None, 0)
+    K = np.array([cfg.K[k] for k in range(9)], np.float32)
+    pose = np.concatenate([R.reshape(9), t]).astype(np.float32)
+    in_view = np.zeros(m, np.uint8)
+    proj = np.zeros((m, 2), np.float32)
+    depth = np.zeros(m, np.float32)
+    vc = np.full(m, np.nan, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.ppg_check_in_frustum.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4
+    rc = L.ppg_check_in_frustum(C.c_void_p(g), p(K), p(pose), m, p(pos), p(nrm), p(dmin), p(dmax), C.c_float(0.5),
+                                p(in_view), p(proj), p(depth), p(vc))
+    L.ppg_grid_free(C.c_void_p(g))
+    assert rc == 0
+    mp = {"pos": pos, "normal": nrm, "min_dist": dmin, "max_dist": dmax, "desc": np.zeros((m, 256), np.float32),
+          "bad": np.zeros(m, np.uint8), "nobs": np.zeros(m, np.int32)}
+    o_in, o_proj, o_depth, o_vc = orc.check_in_frustum(ocfg, R, t, mp, 0.5)
+    assert 20 < int(o_in.sum()) < m - 20
+    assert np.array_equal(in_view, o_in) and np.array_equal(proj, o_proj) and np.array_equal(depth, o_depth)
+    assert np.array_equal(vc, o_vc, equal_nan=True)
+    assert np.all(proj[in_view == 0] == -1) and np.all(depth[in_view == 0] == -1)
