@@ -136,7 +136,10 @@ class Context:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may be gone already
+            pass
 
     def _chk(self, rc):
         if rc != 0:

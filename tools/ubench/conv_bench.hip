@@ -37,7 +37,7 @@ __global__ void fill_rand8(uint8_t* p, size_t n) {
 }
 struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, nbuf, ks = 3; };
 int main(int argc, char** argv) {
-    const int B = 16;
+    const int B = argc > 2 ? atoi(argv[2]) : 16;
     std::vector<L> ls = {
         {"conv1b fused pool", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 1},
         {"conv1b fused pool nbuf2", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 2},
