@@ -70,9 +70,27 @@ def cpu_baseline(H, W, kind, max_num, seconds=12.0):
         if dt > seconds or n >= 64:
             break
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} consecutive {W}x{H} '{kind}' frames, extract + all-pairs match vs previous frame; "
-                      f"conv stack OpenMP over {cores} threads, post-processing and matcher single-threaded"}
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{n} consecutive {W}x{H} '{kind}' frames, extract + all-pairs match vs previous frame; "
+                     f"conv stack OpenMP over {cores} threads, post-processing and matcher single-threaded"}
+    # What the reference's LibTorch CPU path spends in its four networks: the same ATen op sequence (conv2d, max_pool2d,
+    # batch_norm, pixel_shuffle) over the extracted weights, torch CPU, same thread count.  CNN only; a bounded sample.
+    try:
+        import torch
+        from oracle.aten_cnn import AtenNets
+        torch.set_num_threads(cores)
+        nets = AtenNets()
+        img = synth.frame_from_scene(scene, H, W, 0)
+        nets.inference(img)
+        k, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 5.0 and k < 64:
+            nets.inference(synth.frame_from_scene(scene, H, W, k + 1))
+            k += 1
+        out["aten_cpu_cnn_only"] = {"value": round(k / (time.perf_counter() - t1), 3), "unit": "frames/s", "cores": cores,
+                                    "sample": f"{k} frames, the four networks only (torch {torch.__version__} CPU ops)"}
+    except Exception as e:  # the baseline is a report, never a reason to fail the bench
+        out["aten_cpu_cnn_only"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():

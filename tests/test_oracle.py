@@ -336,3 +336,21 @@ def test_feature_vector_matchers_small(orc):
     pos2b = pos1 + np.array([2.0, 5.0], np.float32)
     n, pairs = orc.search_for_triangulation(cfg, R, np.zeros(3, np.float32), R, t2, root, root, d, pos1, none, d, pos2b, none)
     assert n == 0
+
+
+def test_aten_op_sequence_matches_goldens_and_oracle(onet, synth):
+    """The plain PyTorch (ATen CPU) op sequence over the extracted weights reproduces the reference archives' outputs
+    (committed goldens) and agrees with the C restatement of the CNN."""
+    from oracle.aten_cnn import AtenNets
+    from conftest import golden
+    nets = AtenNets()
+    g = golden("cnn_96x128_s1_sparse.npz")
+    img = g["img"]
+    feat, junc, heat, desc = nets.inference(img)
+    for name, t in (("feat", feat), ("junc", junc), ("heat", heat), ("desc", desc)):
+        ref = g[name]
+        got = t[0].numpy()
+        assert got.shape == ref.shape
+        assert float(np.abs(got - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max())), name
+    o = onet.inference(img)
+    assert float(np.abs(o["feat"] - feat[0].numpy()).max()) <= 1e-5 * float(np.abs(o["feat"]).max())
