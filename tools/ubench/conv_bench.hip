@@ -1,14 +1,6 @@
 // Isolated timing of the convolution kernel on the layer shapes of the 640x480 front-end (batch 16).
-// Build with -DPPG_UB=<mask> to knock out parts of the kernel (1 stores, 2 fused conv1a arithmetic,
-// 4 stash + barriers, 8 fetch) and see what each costs.  Results are NOT meaningful with a mask.
-#ifndef PPG_UB
-#define PPG_UB 0
-#endif
-#ifdef TRACE
-#include "k_trace.hip"
-#else
+// Usage: conv_bench <0 zeros | 1 random | 2 small positive | 3 denormal-range inputs> [batch]
 #include "../../ppg-slam_amd/csrc/ppg_kernels.hip"
-#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,17 +88,7 @@ int main(int argc, char** argv) {
         double fl = 2.0 * B * l.H * l.W * l.Cin * l.Cout * l.ks * l.ks;
         hipStreamSynchronize(s2);
         hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost);
-#ifdef TRACE
-        if (&l == &ls[0] || &l == &ls[3]) {
-            const int nb = a.tiles_x * a.tiles_y * B; std::vector<unsigned long long> h(4 * 32768);
-            hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_rec), h.size() * 8);
-            char fn[64]; snprintf(fn, sizeof fn, "../../gpurun_out/wgtrace_%d.txt", (int)(&l - &ls[0]));
-            FILE* f = fopen(fn, "w");
-            for (int i = 0; i < nb && i < 32768; i++) fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4*i], h[4*i+1], h[4*i+2], h[4*i+3]);
-            fclose(f);
-        }
-#endif
-        printf("UB=%d rnd=%d %-26s %8.1f us  %6.1f TF/s  blocks=%d  clk=%.0f MHz\n", PPG_UB, (int)rnd, l.name, ms * 1e3, fl / ms / 1e9,
+        printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  blocks=%d  clk=%.0f MHz\n", (int)rnd, l.name, ms * 1e3, fl / ms / 1e9,
                a.tiles_x * a.tiles_y * B * a.nblk, 100.0 * hclk[0] / hclk[1]);
     }
     return 0;
