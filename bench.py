@@ -229,7 +229,7 @@ def main():
             ((o_ms + prof_all["conv1a"][0] + prof_all["conv_other"][0]) * 1e-3) / 1e12
         frames_total = B * args.steps * world
         out = {
-            "metric": "front-end frames/sec (extract+describe+match) @640x480",
+            "metric": f"front-end frames/sec (extract+describe+match) @{W}x{H}",
             "value": round(frames_total / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",

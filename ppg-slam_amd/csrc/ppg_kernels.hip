@@ -596,7 +596,7 @@ __device__ inline void undistort_fisheye_dev(const NmsArgs& a, float x, float y,
     *ov = (float)(fy * (py * scale) + cy);
 }
 
-constexpr int EMIT_SORT_CAP = 8192;  // keys sorted in LDS (64 KiB); larger sets are ranked by counting
+constexpr int EMIT_SORT_CAP = 8192;  // keys sorted in LDS (64 KiB); of larger sets only the best max_num are sorted
 
 __device__ inline void emit_point(const NmsArgs& a, int b, const float* sc, uint32_t p, int rank) {
     const int x = (int)(p % (uint32_t)a.W), y = (int)(p / (uint32_t)a.W);
@@ -616,40 +616,85 @@ __device__ inline void emit_point(const NmsArgs& a, int b, const float* sc, uint
 // order with its early break at JUNCTION_MAX_NUM, PPGExtractor.cpp:180, :195-196).
 __global__ __launch_bounds__(1024) void nms_emit_kernel(NmsArgs a) {
     __shared__ unsigned long long skey[EMIT_SORT_CAP];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int hist[256];
+    __shared__ int wtot[4];
+    __shared__ int s_bin, s_k, s_cnt;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* cnt = a.counters + b * 8;
     const int S = min(cnt[1], a.kept_cap);
     const float* sc = a.score + (size_t)b * a.H * a.W;
     const uint32_t* kept = a.kept + (size_t)b * a.kept_cap;
     const int n = min(S, a.max_num);
+    int m = S;  // keys to sort
     if (S <= EMIT_SORT_CAP) {
-        int P = 1;
-        while (P < S) P <<= 1;
-        for (int k = tid; k < P; k += 1024) skey[k] = k < S ? prio_key(sc[kept[k]], kept[k]) : 0ull;
-        __syncthreads();
-        // bitonic sort, descending
-        for (int size = 2; size <= P; size <<= 1)
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int t = tid; t < (P >> 1); t += 1024) {
-                    const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                    const bool desc = (lo & size) == 0;
-                    const unsigned long long x = skey[lo], y = skey[hi];
-                    if ((x < y) == desc) { skey[lo] = y; skey[hi] = x; }
-                }
-                __syncthreads();
-            }
-        for (int r = tid; r < n; r += 1024) emit_point(a, b, sc, 0xFFFFFFFFu - (uint32_t)(skey[r] & 0xFFFFFFFFull), r);
+        for (int k = tid; k < S; k += 1024) skey[k] = prio_key(sc[kept[k]], kept[k]);
     } else {
+        // More kept pixels than fit the LDS sort: only the best n = max_num are emitted, so find the n-th largest
+        // key by radix select (8 bits per pass over the keys in memory; keys are distinct) and sort just those n.
         unsigned long long* key = a.kept_key + (size_t)b * a.kept_cap;
         for (int k = tid; k < S; k += 1024) key[k] = prio_key(sc[kept[k]], kept[k]);
         __syncthreads();
-        for (int k = tid; k < S; k += 1024) {
-            const unsigned long long mine = key[k];
-            int rank = 0;
-            for (int j = 0; j < S; j++) rank += key[j] > mine;
-            if (rank < n) emit_point(a, b, sc, kept[k], rank);
+        unsigned long long prefix = 0, mask = 0;
+        int kk = n;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int k = tid; k < S; k += 1024) {
+                const unsigned long long u = key[k];
+                if ((u & mask) == prefix) atomicAdd(&hist[(int)((u >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            int c = 0, inc = 0;
+            if (tid < 256) {
+                c = hist[255 - tid];  // bins in descending order
+                inc = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                if (lane == 63) wtot[wave] = inc;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                for (int w = 0; w < wave; w++) inc += wtot[w];
+                const int exc = inc - c;
+                if (exc < kk && kk <= inc) { s_bin = 255 - tid; s_k = kk - exc; }
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)s_bin << shift;
+            mask |= 255ull << shift;
+            kk = s_k;
         }
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (int k = tid; k < S; k += 1024) {
+            const unsigned long long u = key[k];
+            if (u >= prefix) {
+                const int o = atomicAdd(&s_cnt, 1);
+                if (o < EMIT_SORT_CAP) skey[o] = u;
+            }
+        }
+        __syncthreads();
+        m = min(s_cnt, EMIT_SORT_CAP);  // == n
     }
+    int P = 1;
+    while (P < m) P <<= 1;
+    __syncthreads();
+    for (int k = m + tid; k < P; k += 1024) skey[k] = 0ull;
+    __syncthreads();
+    // bitonic sort, descending
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long x = skey[lo], y = skey[hi];
+                if ((x < y) == desc) { skey[lo] = y; skey[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < n; r += 1024) emit_point(a, b, sc, 0xFFFFFFFFu - (uint32_t)(skey[r] & 0xFFFFFFFFull), r);
     if (tid == 0) cnt[3] = n;
 }
 

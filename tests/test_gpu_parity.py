@@ -123,13 +123,17 @@ def test_ragged_sizes_vs_oracle(pkg, orc, onet, synth):
 def test_full_size_postprocessing_exact_on_gpu_tensors(pkg, orc, synth):
     """The benchmark image sizes: every integer output equals the oracle's when both start from the GPU's CNN tensors."""
     for (H, W, seed, kind, maxnum) in ((480, 640, 31, "sparse", 500), (480, 640, 32, "dense", 1024), (512, 512, 33, "dense", 1024),
-                                       (1024, 1024, 34, "sparse", 1024)):
+                                       (1024, 1024, 34, "sparse", 1024), (1024, 1024, 35, "dense", 1024)):
         ctx = get_ctx(pkg, W, H, maxnum)
         img = synth.make_frame(H, W, seed, 0, kind)
         r = ctx.extract(img)
         cfg = orc.default_cfg(W, H, maxnum)
         kp = orc.detect_keypoints(cfg, ctx.read_tensor(pkg.T_SCORE))
         assert r["n"] == kp["n"]
+        if (H, kind) == (1024, "dense"):
+            # more than 8192 NMS survivors: the ranking kernel takes its radix-select path
+            full = orc.default_cfg(W, H, 1 << 20)
+            assert orc.detect_keypoints(full, ctx.read_tensor(pkg.T_SCORE))["n"] > 8192
         assert np.array_equal(r["xy"], kp["xy"]) and np.array_equal(r["score"], kp["score"])
         refined = orc.refine_heat(cfg, ctx.read_tensor(pkg.T_HEAT))
         assert np.array_equal(ctx.read_tensor(pkg.T_HEAT_REFINED), refined)
