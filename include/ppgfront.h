@@ -163,6 +163,16 @@ int ppg_match_nn(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, i
                  float th, float ratio, int mode,
                  int32_t* match12, float* best, float* second, int* n_matches);
 
+/* Mutual nearest neighbours, the agreement check of Matcher::SearchBySim3 (matching/src/Matcher.cpp:1316-1332): row i of
+ * A takes its first argmin j among its candidates when that distance is <= th (vnMatch1, :1230-1260), row j of B takes its
+ * first argmin among ITS candidates likewise (vnMatch2, :1287-1312), and match12[i] = j only if both agree.  cand12 /
+ * cand21: CSR candidate lists for the two directions (the windows around the two projections); both NULL = all pairs.
+ * Both searches run on the GPU (match_plain_kernel, wave-shuffle argmin); *n_matches = nFound. */
+int ppg_match_mutual(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, int dim,
+                     const int32_t* cand12_off, const int32_t* cand12_idx,
+                     const int32_t* cand21_off, const int32_t* cand21_idx,
+                     float th, int32_t* match12, int* n_matches);
+
 /* Matcher::SearchForInitialization (matching/include/Matcher.h:40, Matcher.cpp:582-651).
  * pos2: F2.mvKeysUn[i].mPos; prev_matched (2*n1, in/out) = vbPrevMatched; window <= 0 = all pairs. */
 int ppg_search_for_initialization(ppg_ctx* ctx, float nnratio,

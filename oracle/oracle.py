@@ -52,7 +52,7 @@ def lib():
 
 
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 def default_cfg(width, height, max_num=500):
@@ -236,6 +236,42 @@ def search_for_triangulation(cfg, R1, t1, R2, t2, fv1, fv2, desc1, pos1, mp1, de
     n = lib().ppgo_search_for_triangulation(C.byref(cfg), C.byref(p1), C.byref(p2), C.byref(a), C.byref(b), int(desc1.shape[0]),
                                             _p(desc1), _p(pos1), _p(mp1), int(desc2.shape[0]), _p(desc2), _p(pos2), _p(mp2), _p(pairs))
     return n, pairs[:n].copy()
+
+
+def window_nn(q, desc, cand, skip=None):
+    """First argmin of DescriptorDistance over the candidate list (Matcher.cpp:57-82); returns (idx or -1, best, second)."""
+    q = np.ascontiguousarray(q, np.float32)
+    desc = np.ascontiguousarray(desc, np.float32)
+    cand = np.ascontiguousarray(cand, np.int32)
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    best, second = C.c_float(0), C.c_float(0)
+    L = lib()
+    L.ppgo_window_nn.restype = C.c_int
+    i = L.ppgo_window_nn(_p(q), int(desc.shape[1]), _p(desc), _p(cand), int(cand.shape[0]), _p(sk), C.byref(best), C.byref(second))
+    return int(i), best.value, second.value
+
+
+def mutual_nn(A, B, th, cand12=None, cand21=None):
+    """The agreement check of Matcher::SearchBySim3 (Matcher.cpp:1230-1260, 1287-1332) over two candidate structures."""
+    nA, nB = len(A), len(B)
+    def side(X, Y, cand):
+        out = np.full(len(X), -1, np.int32)
+        for i in range(len(X)):
+            c = np.arange(len(Y), dtype=np.int32) if cand is None else np.asarray(cand[1][cand[0][i]:cand[0][i + 1]], np.int32)
+            if len(c) == 0:
+                continue
+            j, best, _ = window_nn(X[i], Y, c)
+            if j >= 0 and best <= th:
+                out[i] = j
+        return out
+    m1, m2 = side(A, B, cand12), side(B, A, cand21)
+    m12 = np.full(nA, -1, np.int32)
+    n = 0
+    for i1 in range(nA):
+        if m1[i1] >= 0 and m2[m1[i1]] == i1:
+            m12[i1] = m1[i1]
+            n += 1
+    return n, m12
 
 
 def distinctive_descriptor(desc):

@@ -318,6 +318,20 @@ class Context:
         self._chk(rc)
         return in_view, proj, depth, vc
 
+    def match_mutual(self, A, B, th, cand12=None, cand21=None):
+        """Mutual nearest neighbours (Matcher::SearchBySim3's agreement check); cand = (off, idx) per direction or None."""
+        A = np.ascontiguousarray(A, np.float32)
+        B = np.ascontiguousarray(B, np.float32)
+        m12 = np.full(A.shape[0], -1, np.int32)
+        n = C.c_int(0)
+        o12 = i12 = o21 = i21 = None
+        if cand12 is not None:
+            o12, i12 = np.ascontiguousarray(cand12[0], np.int32), np.ascontiguousarray(cand12[1], np.int32)
+            o21, i21 = np.ascontiguousarray(cand21[0], np.int32), np.ascontiguousarray(cand21[1], np.int32)
+        self._chk(self.L.ppg_match_mutual(C.c_void_p(self.h), _p(A), A.shape[0], _p(B), B.shape[0], A.shape[1], _p(o12), _p(i12),
+                                          _p(o21), _p(i21), C.c_float(th), _p(m12), C.byref(n)))
+        return n.value, m12
+
     def distinctive_descriptors(self, desc, seg_off):
         """MapPoint::ComputeDistinctiveDescriptors for every segment of `desc` rows; returns BestIdx per segment."""
         desc = np.ascontiguousarray(desc, np.float32)

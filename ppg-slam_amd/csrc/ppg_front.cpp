@@ -1230,6 +1230,31 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     return PPG_OK;
 }
 
+int ppg_match_mutual(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int dim, const int32_t* o12,
+                     const int32_t* i12, const int32_t* o21, const int32_t* i21, float th, int32_t* match12, int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (nA < 0 || nB < 0 || (nA && !match12) || ((o12 == nullptr) != (i12 == nullptr)) || ((o21 == nullptr) != (i21 == nullptr)) ||
+        ((o12 == nullptr) != (o21 == nullptr)))
+        return fail(c, PPG_EINVAL, "ppg_match_mutual: bad argument");
+    if (n_matches) *n_matches = 0;
+    for (int i = 0; i < nA; i++) match12[i] = -1;
+    if (nA == 0 || nB == 0) return PPG_OK;
+    std::vector<int32_t> m1(nA, -1), m2(nB, -1);
+    std::vector<float> b1(nA), b2(nB);
+    int rc = ppg_match_nn(c, A, nA, B, nB, dim, o12, i12, nullptr, th, 0.f, PPG_MATCH_PLAIN, m1.data(), b1.data(), nullptr, nullptr);
+    if (!rc) rc = ppg_match_nn(c, B, nB, A, nA, dim, o21, i21, nullptr, th, 0.f, PPG_MATCH_PLAIN, m2.data(), b2.data(), nullptr, nullptr);
+    if (rc) return rc;
+    int nFound = 0;
+    for (int i1 = 0; i1 < nA; i1++) {
+        const int idx2 = (m1[i1] >= 0 && b1[i1] <= th) ? m1[i1] : -1;   // :1254-1257
+        if (idx2 < 0) continue;
+        const int idx1 = (m2[idx2] >= 0 && b2[idx2] <= th) ? m2[idx2] : -1;  // :1309-1312
+        if (idx1 == i1) { match12[i1] = idx2; nFound++; }
+    }
+    if (n_matches) *n_matches = nFound;
+    return PPG_OK;
+}
+
 }  // extern "C"
 
 // ---- Frame grid (host integer logic) ----

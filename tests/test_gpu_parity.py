@@ -566,3 +566,29 @@ def test_lens_distortion_path_vs_oracle(fisheye, D, pkg, orc, synth):
         assert np.array_equal(r["conn_idx"], ln["conn_idx"]) and np.array_equal(r["coline_pairs"], ln["coline_pairs"])
     finally:
         ctx.close()
+
+
+def test_match_mutual_vs_oracle(pkg, orc):
+    """Mutual nearest neighbours (the agreement check of Matcher::SearchBySim3): all pairs and with candidate windows."""
+    rng = np.random.default_rng(9)
+    ctx = get_ctx(pkg, 128, 96)
+    nA, nB = 300, 260
+    base = rng.standard_normal((320, 256)).astype(np.float32)
+    A = base[:nA] + 0.25 * rng.standard_normal((nA, 256)).astype(np.float32)
+    B = base[rng.permutation(320)[:nB]] + 0.25 * rng.standard_normal((nB, 256)).astype(np.float32)
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    B /= np.linalg.norm(B, axis=1, keepdims=True)
+    n, m12 = ctx.match_mutual(A, B, 0.8)
+    on, om = orc.mutual_nn(A, B, 0.8)
+    assert n == on and n > 100 and np.array_equal(m12, om)
+    # windows: each row sees a random third of the other side, independently per direction
+    def windows(n1, n2):
+        off, idx = [0], []
+        for i in range(n1):
+            idx.extend(np.sort(rng.choice(n2, n2 // 3, replace=False)).tolist() if i % 11 else [])
+            off.append(len(idx))
+        return np.array(off, np.int32), np.array(idx, np.int32)
+    c12, c21 = windows(nA, nB), windows(nB, nA)
+    n, m12 = ctx.match_mutual(A, B, 0.8, c12, c21)
+    on, om = orc.mutual_nn(A, B, 0.8, c12, c21)
+    assert n == on and 5 < n < 150 and np.array_equal(m12, om)
