@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_bf16: 32768 FLOP per 32 clk per SIMD x 1024 SIMDs x 2.4 GHz
 PREROLL = 24                   # untimed steps guaranteed before the timed region (see main)
 
 
@@ -104,6 +105,8 @@ def main():
     ap.add_argument("--max-num", type=int, default=1024, help="JUNCTION_MAX_NUM (1024-keypoint match config)")
     ap.add_argument("--kind", default="dense")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", type=int, default=0,
+                    help="0 fp32 (the parity path, the default and the number of record), 1 bf16 hi/lo split, 2 plain bf16")
     ap.add_argument("--host-input", action="store_true",
                     help="hand over host buffers (upload inside the timed region): the PCIe-inclusive rate, never the headline")
     args = ap.parse_args()
@@ -125,7 +128,8 @@ def main():
     pkg = load_pkg()
     synth = importlib.import_module("ppg_slam_amd.synth")
     H, W, B = args.height, args.width, args.batch
-    ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=args.max_num, device_id=local_rank))
+    ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=args.max_num, device_id=local_rank,
+                                         precision=args.precision))
 
     # B streams per rank; stream s of rank r is scene seed 1000*(r*B+s)+11; 8 consecutive frames of
     # every stream are staged in HBM and replayed round-robin.
@@ -228,24 +232,29 @@ def main():
         all_conv_tf = (fl_all["conv3x3"] + fl_all["conv1a"] + fl_all["conv_other"]) / \
             ((o_ms + prof_all["conv1a"][0] + prof_all["conv_other"][0]) * 1e-3) / 1e12
         frames_total = B * args.steps * world
+        # roofline of the dominant kernel in algorithmic FLOPs: the bf16 split executes three bf16 MFMAs per product
+        peak = (FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS / 3.0, BF16_MFMA_PEAK_TFLOPS)[args.precision]
+        cnn_txt = ("CNN fp32 MFMA", "CNN 3x3 layers on the bf16 MFMA with hi/lo split operands (3 products), fp32 accumulate",
+                   "CNN 3x3 layers on the bf16 MFMA (plain bf16 operands), fp32 accumulate")[args.precision]
+        kname = ("conv_mfma_kernel<3,2,8,true,32>", "conv_bf16_kernel<2,true,32,3>", "conv_bf16_kernel<2,true,32,1>")[args.precision]
         out = {
             "metric": f"front-end frames/sec (extract+describe+match) @{W}x{H}",
             "value": round(frames_total / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("f32", "bf16x3", "bf16")[args.precision], "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic '{args.kind}' scenes, {B} camera streams per GPU per step, "
-                                   f"full extract (CNN fp32 MFMA + NMS + line graph + descriptors, JUNCTION_MAX_NUM={args.max_num}) "
+                                   f"full extract ({cnn_txt} + NMS + line graph + descriptors, JUNCTION_MAX_NUM={args.max_num}) "
                                    f"+ all-pairs SearchForInitialization match vs previous frame; " + ("input handed over as host buffers" if args.host_input else "input resident in HBM"),
                        "batch_per_gpu": B, "parallelism": f"stream-sharded x{world}, RCCL all-reduce(MIN) barrier per step",
                        "avg_keypoints": round(timed["kp"] / (B * args.steps), 1),
                        "avg_edges": round(timed["edges"] / (B * args.steps), 1),
                        "avg_matches": round(timed["matches"] / (B * args.steps), 1)},
             "roofline": {"bound": "mfma",
-                         "kernel": "conv_mfma_kernel<3,2,8,true,32>: conv1a (1->64, on the fly) + conv1b (64->64, 3x3) + ReLU + "
+                         "kernel": kname + ": conv1a (1->64, on the fly) + conv1b (64->64, 3x3) + ReLU + "
                                    "2x2 max-pool at full resolution; 40 % of the front-end's FLOPs, the longest launch of a step",
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(dom_launches),
                          "flops_per_launch": flops_per_launch, "traffic": None,
                          "other_3x3_convolutions": {"kernel": "conv_mfma_kernel<3,2,8,false,32|16> (six launches per step)",
@@ -260,7 +269,8 @@ def main():
         if os.path.exists(tr):
             try:
                 tj = json.load(open(tr))
-                if tj.get("batch") == B and tj.get("width") == W and tj.get("height") == H:
+                if tj.get("batch") == B and tj.get("width") == W and tj.get("height") == H and \
+                        tj.get("precision", 0) == args.precision:
                     out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
             except Exception:
                 pass

@@ -73,8 +73,9 @@ class Net:
             lib().ppgo_net_free(C.c_void_p(self.h))
             self.h = None
 
-    def inference(self, img):
-        """img: (H, W) uint8 -> dict of NCHW float32 arrays like the reference tensors."""
+    def inference(self, img, precision=0):
+        """img: (H, W) uint8 -> dict of NCHW float32 arrays like the reference tensors.  precision 1 / 2: the
+        build's bf16-split / plain-bf16 convolution modes instead of fp32."""
         img = np.ascontiguousarray(img, dtype=np.uint8)
         H, W = img.shape
         h, w = H // 8, W // 8
@@ -82,7 +83,8 @@ class Net:
         junc = np.empty((65, h, w), np.float32)
         heat = np.empty((2, H, W), np.float32)
         desc = np.empty((256, h, w), np.float32)
-        rc = lib().ppgo_inference(C.c_void_p(self.h), _p(img), H, W, _p(feat), _p(junc), _p(heat), _p(desc))
+        rc = lib().ppgo_inference_prec(C.c_void_p(self.h), _p(img), H, W, int(precision), _p(feat), _p(junc), _p(heat),
+                                       _p(desc))
         if rc != 0:
             raise RuntimeError("ppgo_inference failed")
         return dict(feat=feat, junc=junc, heat=heat, desc=desc)

@@ -160,6 +160,45 @@ void conv3x3(const std::vector<float>& in, int H, int W, const Conv& c, std::vec
     }
 }
 
+// Reduced-precision modes of the build's convolution (no counterpart in the reference, whose CUDA path leaves the
+// operand precision to cuDNN: every conv of net/*.pt is traced with allow_tf32=True).  Every fp32 operand v is
+// split into bf16 hi = rne(v) and lo = rne(v - hi); terms = 3 evaluates w_hi*x_hi + w_hi*x_lo + w_lo*x_hi,
+// terms = 1 only w_hi*x_hi, products exact, accumulated in fp32.  Stated as an ordinary convolution over
+// concatenated channel planes, so the accumulation order is that of conv3x3.
+inline float bf16_round(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
+}
+
+void conv3x3_lowp(const std::vector<float>& in, int H, int W, const Conv& c, int terms, std::vector<float>& out) {
+    const int Cin = c.cin, Cout = c.cout, C2 = terms * Cin;
+    std::vector<float> in2((size_t)H * W * C2);
+    for (size_t p = 0; p < (size_t)H * W; p++)
+        for (int ci = 0; ci < Cin; ci++) {
+            const float v = in[p * Cin + ci], hi = bf16_round(v), lo = bf16_round(v - hi);
+            in2[p * C2 + ci] = hi;
+            if (terms == 3) { in2[p * C2 + Cin + ci] = lo; in2[p * C2 + 2 * Cin + ci] = hi; }
+        }
+    Conv c2;
+    c2.cin = C2; c2.cout = Cout; c2.ks = 3; c2.b = c.b;
+    c2.w.resize((size_t)9 * C2 * Cout);
+    for (int t = 0; t < 9; t++)
+        for (int ci = 0; ci < Cin; ci++)
+            for (int o = 0; o < Cout; o++) {
+                const float v = c.w[((size_t)t * Cin + ci) * Cout + o], hi = bf16_round(v), lo = bf16_round(v - hi);
+                c2.w[((size_t)t * C2 + ci) * Cout + o] = hi;
+                if (terms == 3) {
+                    c2.w[((size_t)t * C2 + Cin + ci) * Cout + o] = hi;
+                    c2.w[((size_t)t * C2 + 2 * Cin + ci) * Cout + o] = lo;
+                }
+            }
+    conv3x3(in2, H, W, c2, out);
+}
+
 void conv1x1(const std::vector<float>& in, int H, int W, const Conv& c, std::vector<float>& out) {
     const int Cin = c.cin, Cout = c.cout;
     out.assign((size_t)H * W * Cout, 0.0f);
@@ -246,7 +285,19 @@ void ppgo_net_free(ppgo_net* n) { delete n; }
 
 int ppgo_inference(const ppgo_net* n, const uint8_t* img, int H, int W,
                    float* feat, float* junc, float* heat, float* desc) {
-    if (!n || H % 8 || W % 8) return -1;
+    return ppgo_inference_prec(n, img, H, W, 0, feat, junc, heat, desc);
+}
+
+// precision 0: fp32 (the reference graphs as torch evaluates them on the CPU); 1 / 2: the build's bf16 split /
+// plain bf16 modes, applied to the layers the build applies them to (every 3x3 convolution whose input has a
+// multiple of 16 channels and whose output has at least 64: all but conv1a and the 16 -> 16 EdgeHeatmap block).
+int ppgo_inference_prec(const ppgo_net* n, const uint8_t* img, int H, int W, int precision,
+                        float* feat, float* junc, float* heat, float* desc) {
+    if (!n || H % 8 || W % 8 || precision < 0 || precision > 2) return -1;
+    auto conv3x3 = [&](const std::vector<float>& in, int h_, int w_, const Conv& cv, std::vector<float>& out) {
+        if (precision != 0 && cv.cin % 16 == 0 && cv.cout >= 64) conv3x3_lowp(in, h_, w_, cv, precision == 1 ? 3 : 1, out);
+        else ::conv3x3(in, h_, w_, cv, out);
+    };
     std::vector<float> a((size_t)H * W), b, c;
     // PPGExtractor.cpp:151 — uint8 -> float, then a true division by 255
     for (size_t i = 0; i < a.size(); i++) a[i] = (float)img[i] / 255.0f;

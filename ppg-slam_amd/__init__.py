@@ -85,9 +85,11 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def default_config(width, height, max_batch=1, max_num=500, weights=DEFAULT_WEIGHTS, device_id=0):
+def default_config(width, height, max_batch=1, max_num=500, weights=DEFAULT_WEIGHTS, device_id=0, precision=0):
+    """precision: 0 fp32 (parity path), 1 bf16 hi/lo split with three products, 2 plain bf16 (3x3 convolutions)."""
     cfg = Config()
     lib().ppg_default_config(C.byref(cfg), width, height)
+    cfg.precision = precision
     cfg.max_batch = max_batch
     cfg.junction_max_num = max_num
     cfg.device_id = device_id

@@ -32,6 +32,7 @@ struct Tensor {
 struct DevConv {
     int ks = 3, nt = 2, cin = 0, cout = 0, nblk = 0;
     float *w = nullptr, *bias = nullptr, *alpha = nullptr, *beta = nullptr;
+    bool lowp = false;  // w holds the bf16 hi/lo image of conv_bf16_kernel (reduced-precision modes)
 };
 
 template <class T>
@@ -322,6 +323,19 @@ int upload(ppg_ctx* c, T** p, const std::vector<T>& v) {
     return PPG_OK;
 }
 
+// float -> bf16 bits, round to nearest even (finite inputs), and back
+inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
 // Pack OIHW weights into the LDS image order of conv_mfma_kernel:
 //   [cout block][cin chunk][group of 8 cin][tap][half h][cout in block][4 cin]
 // with cin = chunk*KC + g*8 + h*4 + s.  `ps2` permutes couts so that a pixel-shuffle block's packed
@@ -359,6 +373,32 @@ int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::str
                                 pk[dst] = w.v[((size_t)o * cin + ci) * taps + tap];
                             }
                         }
+    // Reduced-precision modes: the 3x3 layers with 64-cout blocks run on the bf16 MFMA.  Image order of
+    // conv_bf16_kernel: [cout block][chunk of 16 cin][tap][half h][hi | lo][cout in block][8 cin], cin = chunk*16 +
+    // h*8 + j; hi = bf16(w) rounded to nearest even, lo = bf16(w - hi).  Same byte count as the fp32 image.
+    dc.lowp = c->cfg.precision != 0 && ks == 3 && nt == 2 && cin % 16 == 0;
+    if (dc.lowp) {
+        std::vector<uint16_t> pb(pk.size() * 2, 0);
+        const int nch16 = cin / 16;
+        for (int nb = 0; nb < nblk; nb++)
+            for (int ch = 0; ch < nch16; ch++)
+                for (int tap = 0; tap < taps; tap++)
+                    for (int h = 0; h < 2; h++)
+                        for (int nn = 0; nn < NB; nn++) {
+                            const int o = orig(nb * NB + nn);
+                            if (o < 0) continue;
+                            for (int j = 0; j < 8; j++) {
+                                const int ci = ch * 16 + h * 8 + j;
+                                const float wv = w.v[((size_t)o * cin + ci) * taps + tap];
+                                const uint16_t hi = bf16_rne(wv);
+                                const uint16_t lo = bf16_rne(wv - bf16_float(hi));
+                                const size_t base = (((((size_t)nb * nch16 + ch) * taps + tap) * 2 + h) * 2) * NB;
+                                pb[((base + nn) * 8) + j] = hi;
+                                pb[((base + NB + nn) * 8) + j] = lo;
+                            }
+                        }
+        memcpy(pk.data(), pb.data(), pk.size() * sizeof(float));
+    }
     std::vector<float> bias((size_t)nblk * NB, 0.f), alpha, beta;
     for (int cp = 0; cp < nblk * NB; cp++) {
         const int o = orig(cp);
@@ -489,7 +529,7 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
              const uint8_t* fused_img = nullptr) {
     ppg::ConvArgs a;
     if (fused_img) { a.img = fused_img; a.w1a = c->c1a_w; a.b1a = c->c1a_b; }
-    a.in = in; a.wpk = dc.w;
+    a.in = in; a.wpk = dc.w; a.prec = dc.lowp ? c->cfg.precision : 0;
     a.B = n; a.H = H; a.W = W; a.Cin = dc.cin;
     a.mw = fused_img ? 32 : pick_tile(dc, H, W, mode);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw); a.nblk = dc.nblk;
@@ -506,7 +546,7 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
 // 12 cout blocks instead of three with 4, so the small 1/8-resolution grid fills the chip better.
 int run_heads(ppg_ctx* c, int n, int H, int W) {
     ppg::ConvArgs a;
-    a.in = c->feat; a.wpk = c->heads_w;
+    a.in = c->feat; a.wpk = c->heads_w; a.prec = c->pa.lowp ? c->cfg.precision : 0;
     a.B = n; a.H = H; a.W = W; a.Cin = c->pa.cin;
     a.mw = pick_tile(c->pa, H, W, ppg::CONV_PLAIN);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
@@ -624,7 +664,7 @@ static int create_impl(ppg_ctx* c) {
     if (f.junction_max_num < 1 || f.junction_max_num > 4096) return fail(c, PPG_EINVAL, "junction_max_num must be 1..4096");
     if (f.max_batch < 1 || f.max_batch > 64) return fail(c, PPG_EINVAL, "max_batch must be 1..64");
     if (f.heatmap_refine_sz < 1 || f.heatmap_refine_sz > 16) return fail(c, PPG_EINVAL, "heatmap_refine_sz must be 1..16");
-    if (f.precision != 0) return fail(c, PPG_EINVAL, "precision %d is not built", f.precision);
+    if (f.precision < 0 || f.precision > 2) return fail(c, PPG_EINVAL, "precision %d is not built", f.precision);
     if (!f.weights_path) return fail(c, PPG_EINVAL, "weights_path is NULL");
     c->weights_path = f.weights_path;
     c->cfg.weights_path = c->weights_path.c_str();

@@ -15,6 +15,85 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load from a 4-byte aligned address
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Epilogue of the convolution kernels: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store.
+// acc[m][n] is the 32 x 32 result of pixel tile m and cout tile n in the MFMA D layout (lane = pixel l&31,
+// register r = cout (r&3) + 8*(r>>2) + 4*(l>>5)).
+template <int NT, int MW>
+__device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc)[2][NT], int wave, int li, int lh, int x0,
+                                           int y0, int b, int nb) {
+    constexpr int NB = 32 * NT;
+    auto prow = [&](int m, int i) { return MW == 32 ? 2 * wave + m : 4 * wave + 2 * m + (i >> 4); };
+    auto pcol = [&](int i) { return MW == 32 ? i : (i & 15); };
+    // A launch may serve up to three layers that read the same input (cout blocks [nblk0, next nblk0) each).
+    // The lane owns one pixel of each pixel tile and, per cout tile, four runs of four consecutive couts
+    // (registers 4j..4j+3 = couts 8j + 4*(l>>5) + 0..3): one 16-byte store per run.
+    int gi = 0;
+    if (a.ngroups > 1 && nb >= a.g[1].nblk0) gi = 1;
+    if (a.ngroups > 2 && nb >= a.g[2].nblk0) gi = 2;
+    const ConvGroup G = a.g[gi];
+    const int cb = (nb - G.nblk0) * NB;  // first cout of this block inside its layer (packed order)
+    const bool bn = G.alpha != nullptr;
+    const bool vec = (G.Cout & 3) == 0;  // rows of the output are 16-byte aligned
+    const int Cps = G.Cout >> 2;
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int co = cb + n * 32 + 8 * j + 4 * lh;  // first of the four couts
+            if (co >= G.Cout) continue;
+            const f32x4 bias = *(const f32x4*)(G.bias + co);
+            f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+            if (bn) { al = *(const f32x4*)(G.alpha + co); be = *(const f32x4*)(G.beta + co); }
+            if (G.mode == CONV_POOL2) {
+                if (MW != 32) continue;  // pooled layers always use the 8 x 32 tile
+                // rows 2*wave, 2*wave+1 are the two pixel tiles; the column neighbour is the next lane
+                const int y = y0 + 2 * wave, x = x0 + li;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float t = fmaxf(acc[0][n][4 * j + e], acc[1][n][4 * j + e]);
+                    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+                    float r = fmaxf(t, o) + bias[e];
+                    if (G.relu) r = fmaxf(r, 0.f);
+                    v[e] = r;
+                }
+                if ((li & 1) == 0 && y + 1 < a.H && x + 1 < a.W) {
+                    float* dst = G.out + ((size_t)(b * (a.H / 2) + (y >> 1)) * (a.W / 2) + (x >> 1)) * G.Cout + co;
+                    if (vec) *(f32x4*)dst = v;
+                    else
+                        for (int e = 0; e < 4; e++)
+                            if (co + e < G.Cout) dst[e] = v[e];
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const int y = y0 + prow(m, li), x = x0 + pcol(li);
+                    if (y >= a.H || x >= a.W) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float r = acc[m][n][4 * j + e] + bias[e];
+                        if (bn) r = r * al[e] + be[e];
+                        if (G.relu) r = fmaxf(r, 0.f);
+                        v[e] = r;
+                    }
+                    float* dst;
+                    if (G.mode == CONV_PLAIN) {
+                        dst = G.out + ((size_t)(b * a.H + y) * a.W + x) * G.Cout + co;
+                    } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx; Cps is a multiple of 4
+                        const int q = co / Cps, cc = co - q * Cps;
+                        dst = G.out + ((size_t)(b * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1)) * Cps + cc;
+                    }
+                    if (vec) *(f32x4*)dst = v;
+                    else
+                        for (int e = 0; e < 4; e++)
+                            if (co + e < G.Cout) dst[e] = v[e];
+                }
+            }
+        }
+    }
+}
+
 // =====================================================================================
 // Convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32: each product is one fmaf into
 // the accumulator, so the result is a k-ordered fmaf chain).
@@ -50,7 +129,6 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     constexpr int PSTR = KC + 4;
     constexpr int NB = 32 * NT;
     constexpr int TAPS = KS * KS;
-    constexpr int IN_FLOATS = IN_PIX * PSTR;
     constexpr int W_FLOATS = TAPS * KC * NB;
     constexpr int QPP = KC / 4;
     constexpr int IN_ITEMS = IN_PIX * QPP;
@@ -209,75 +287,206 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store ----
-    // A launch may serve up to three layers that read the same input (cout blocks [nblk0, next nblk0) each).
-    // The lane owns one pixel of each pixel tile and, per cout tile, four runs of four consecutive couts
-    // (registers 4j..4j+3 = couts 8j + 4*(l>>5) + 0..3): one 16-byte store per run.
-    int gi = 0;
-    if (a.ngroups > 1 && nb >= a.g[1].nblk0) gi = 1;
-    if (a.ngroups > 2 && nb >= a.g[2].nblk0) gi = 2;
-    const ConvGroup G = a.g[gi];
-    const int cb = (nb - G.nblk0) * NB;  // first cout of this block inside its layer (packed order)
-    const bool bn = G.alpha != nullptr;
-    const bool vec = (G.Cout & 3) == 0;  // rows of the output are 16-byte aligned
-    const int Cps = G.Cout >> 2;
+    conv_store<NT, MW>(a, acc, wave, li, lh, x0, y0, b, nb);
+}
+
+// =====================================================================================
+// The same 3x3 convolution on v_mfma_f32_32x32x16_bf16 for the two reduced-precision modes:
+//   TERMS = 3  every fp32 operand x is split into bf16 hi = rne(x) and lo = rne(x - hi), and the product is
+//              evaluated as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi with fp32 accumulation (about 16 bits of each operand;
+//              three MFMAs that run 16x faster than the fp32 one);
+//   TERMS = 1  plain bf16 operands (w_hi*x_hi only).
+// Activations stay fp32 in memory: the split happens once per staged element on its way into LDS (weights are split
+// on the host when they are packed), so every layer reads and writes exactly what the fp32 kernel does and the two
+// kinds of kernel can be mixed layer by layer.
+//
+// Same work-group tile, wave layout, D layout and epilogue as conv_mfma_kernel.  A chunk is 16 input channels = the K
+// of one MFMA: lanes 0-31 supply channels 0-7 of their pixel (B operand) / cout (A operand), lanes 32-63 channels
+// 8-15.  LDS image of a pixel: [half 0: 8 hi | 8 lo][half 1: 8 hi | 8 lo] + 16 bytes of padding (80-byte stride: the
+// 16-byte fragment reads of 16 consecutive pixels fall on distinct banks); weights [tap][half][hi|lo][cout][8 bf16].
+// =====================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two floats -> their bf16 hi parts and the bf16 of the remainders, each pair packed into one dword
+__device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 x = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+    const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+template <int NT, bool FUSE1A, int MW, int TERMS>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
+    constexpr int KC = 16;
+    constexpr int TW = MW, TH = 256 / MW;
+    constexpr int IH = TH + 2, IW = TW + 2, IN_PIX = IH * IW;
+    constexpr int PSTR = 80;  // bytes per staged pixel
+    constexpr int NB = 32 * NT;
+    constexpr int IN_ITEMS = IN_PIX * 2;  // item = 8 channels of a pixel
+    constexpr int IN_PER_T = (IN_ITEMS + 255) / 256;
+    constexpr int IN_BYTES_P = (IN_PER_T * 256 / 2) * PSTR;
+    constexpr int W_BYTES = 9 * 2 * 2 * NB * 16;
+    constexpr int W_PER_T = (W_BYTES / 16 + 255) / 256;
+    constexpr int W_BYTES_P = W_PER_T * 256 * 16;
+    constexpr int PH = IH + 2, PW = IW + 2;
+    constexpr int FUSE_FLOATS = FUSE1A ? (PH * PW + 9 * 64 + 64) : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IN_BYTES_P + W_BYTES_P + FUSE_FLOATS * 4];
+    float* patch = (float*)(smem + IN_BYTES_P + W_BYTES_P);  // [PH][PW]
+    float* w1s = patch + PH * PW;                             // [9][64]
+    float* b1s = w1s + 9 * 64;                                // [64]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int bx = blockIdx.x;
+    const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, b = bx / (a.tiles_x * a.tiles_y);
+    const int nb = blockIdx.y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int nchunks = a.Cin / KC;
+    auto prow = [&](int m, int i) { return MW == 32 ? 2 * wave + m : 4 * wave + 2 * m + (i >> 4); };
+    auto pcol = [&](int i) { return MW == 32 ? i : (i & 15); };
+
+    // fetch slots: (pixel, half).  Padding pixels and slots past the tile carry an offset outside the buffer (it stays
+    // outside when 16 is added for the second load), for which a buffer load returns zeros.
+    constexpr unsigned NOWHERE = 0x80000000u;
+    unsigned gofs[IN_PER_T];
+    int lofs[IN_PER_T];
 #pragma unroll
-    for (int n = 0; n < NT; n++) {
+    for (int k = 0; k < IN_PER_T; k++) {
+        const int item = tid + 256 * k;
+        // FUSE1A: the four lanes of an MFMA 4x4 block share a half and own four different pixels
+        const int pix = FUSE1A ? 128 * k + (tid >> 3) * 4 + (tid & 3) : item >> 1;
+        const int hh = FUSE1A ? (tid >> 2) & 1 : item & 1;
+        const int py = pix / IW, px = pix % IW;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        lofs[k] = pix * PSTR + hh * 32;
+        gofs[k] = NOWHERE;
+        if (pix < IN_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            gofs[k] = FUSE1A ? (unsigned)(py * PW + px) : (unsigned)(((gy * a.W + gx) * a.Cin + hh * 8) * 4);
+    }
+    int pofs[IN_PER_T];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int co = cb + n * 32 + 8 * j + 4 * lh;  // first of the four couts
-            if (co >= G.Cout) continue;
-            const f32x4 bias = *(const f32x4*)(G.bias + co);
-            f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-            if (bn) { al = *(const f32x4*)(G.alpha + co); be = *(const f32x4*)(G.beta + co); }
-            if (G.mode == CONV_POOL2) {
-                if (MW != 32) continue;  // pooled layers always use the 8 x 32 tile
-                // rows 2*wave, 2*wave+1 are the two pixel tiles; the column neighbour is the next lane
-                const int y = y0 + 2 * wave, x = x0 + li;
-                f32x4 v;
+    for (int k = 0; k < IN_PER_T; k++) pofs[k] = FUSE1A && gofs[k] != NOWHERE ? (int)gofs[k] : 0;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.in + (FUSE1A ? 0 : (size_t)b * a.H * a.W * a.Cin)), 0, FUSE1A ? 0 : a.H * a.W * a.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const unsigned char*)a.wpk + (size_t)nb * nchunks * W_BYTES), 0, nchunks * W_BYTES, 0x00020000);
+    if (FUSE1A) {
+        const uint8_t* im = a.img + (size_t)b * a.H * a.W;
+        for (int i = tid; i < PH * PW; i += 256) {
+            const int gy = y0 - 2 + i / PW, gx = x0 - 2 + i % PW;
+            float v = 0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = (float)im[(size_t)gy * a.W + gx] / 255.0f;
+            patch[i] = v;
+        }
+        for (int i = tid; i < 9 * 64; i += 256) w1s[i] = a.w1a[i];
+        if (tid < 64) b1s[tid] = a.b1a[tid];
+        __syncthreads();
+    }
+
+    f32x4 vin[IN_PER_T][2];
+    u32x4 vw[W_PER_T];
+    auto fetch = [&](int c) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float t = fmaxf(acc[0][n][4 * j + e], acc[1][n][4 * j + e]);
-                    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));  // lane ^ 1
-                    float r = fmaxf(t, o) + bias[e];
-                    if (G.relu) r = fmaxf(r, 0.f);
-                    v[e] = r;
+        for (int k = 0; k < W_PER_T; k++)
+            vw[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + 256 * k) * 16, c * W_BYTES, 0));
+        if (!FUSE1A) {
+#pragma unroll
+            for (int k = 0; k < IN_PER_T; k++)
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    vin[k][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, gofs[k] + 16 * q, c * KC * 4, 0));
+        } else {
+            // conv1a + ReLU in fp32 for the slot's 8 channels (two quads), as in conv_mfma_kernel
+            const int ch = c * KC + ((tid >> 2) & 1) * 8;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const f32x4 bias = *(const f32x4*)(b1s + ch + 4 * q);
+                f32x4 o[IN_PER_T];
+#pragma unroll
+                for (int k = 0; k < IN_PER_T; k++) o[k] = bias;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const float wa = w1s[t * 64 + ch + 4 * q + (tid & 3)];
+#pragma unroll
+                    for (int k = 0; k < IN_PER_T; k++)
+                        o[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa, patch[pofs[k] + (t / 3) * PW + (t % 3)], o[k], 0, 0, 0);
                 }
-                if ((li & 1) == 0 && y + 1 < a.H && x + 1 < a.W) {
-                    float* dst = G.out + ((size_t)(b * (a.H / 2) + (y >> 1)) * (a.W / 2) + (x >> 1)) * G.Cout + co;
-                    if (vec) *(f32x4*)dst = v;
-                    else
-                        for (int e = 0; e < 4; e++)
-                            if (co + e < G.Cout) dst[e] = v[e];
-                }
-            } else {
 #pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    const int y = y0 + prow(m, li), x = x0 + pcol(li);
-                    if (y >= a.H || x >= a.W) continue;
-                    f32x4 v;
+                for (int k = 0; k < IN_PER_T; k++) {
+                    const bool in = gofs[k] != NOWHERE;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float r = acc[m][n][4 * j + e] + bias[e];
-                        if (bn) r = r * al[e] + be[e];
-                        if (G.relu) r = fmaxf(r, 0.f);
-                        v[e] = r;
-                    }
-                    float* dst;
-                    if (G.mode == CONV_PLAIN) {
-                        dst = G.out + ((size_t)(b * a.H + y) * a.W + x) * G.Cout + co;
-                    } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx; Cps is a multiple of 4
-                        const int q = co / Cps, cc = co - q * Cps;
-                        dst = G.out + ((size_t)(b * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1)) * Cps + cc;
-                    }
-                    if (vec) *(f32x4*)dst = v;
-                    else
-                        for (int e = 0; e < 4; e++)
-                            if (co + e < G.Cout) dst[e] = v[e];
+                    for (int e = 0; e < 4; e++) vin[k][q][e] = in ? fmaxf(o[k][e], 0.f) : 0.f;
                 }
             }
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < IN_PER_T; k++) {
+            u32x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                unsigned h0, l0, h1, l1;
+                split_bf16(vin[k][q][0], vin[k][q][1], h0, l0);
+                split_bf16(vin[k][q][2], vin[k][q][3], h1, l1);
+                hi[2 * q] = h0; hi[2 * q + 1] = h1;
+                lo[2 * q] = l0; lo[2 * q + 1] = l1;
+            }
+            *(u32x4*)(smem + lofs[k]) = hi;
+            if (TERMS == 3) *(u32x4*)(smem + lofs[k] + 16) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < W_PER_T; k++) *(u32x4*)(smem + IN_BYTES_P + (tid + 256 * k) * 16) = vw[k];
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+    fetch(0);
+    stash();
+    __syncthreads();
+    const unsigned char* ins = smem;
+    const unsigned char* ws = smem + IN_BYTES_P;
+    for (int c = 0; c < nchunks; c++) {
+        if (c + 1 < nchunks) fetch(c + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+            bf16x8 xh[2], xl[2], wh[NT], wl[NT];
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const unsigned char* p = ins + ((prow(m, li) + ky) * IW + (pcol(li) + kx)) * PSTR + lh * 32;
+                xh[m] = *(const bf16x8*)p;
+                if (TERMS == 3) xl[m] = *(const bf16x8*)(p + 16);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const unsigned char* p = ws + (((tap * 2 + lh) * 2) * NB + n * 32 + li) * 16;
+                wh[n] = *(const bf16x8*)p;
+                if (TERMS == 3) wl[n] = *(const bf16x8*)(p + NB * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) {
+                    if (TERMS == 3) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[n], xh[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[n], xl[m], acc[m][n], 0, 0, 0);
+                    }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[n], xh[m], acc[m][n], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) stash();
+        __syncthreads();
     }
+    conv_store<NT, MW>(a, acc, wave, li, lh, x0, y0, b, nb);
 }
 
 int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
@@ -288,6 +497,20 @@ hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     // one image of the input is addressed as a buffer with 32-bit byte offsets
     if ((long)a.H * a.W * a.Cin * 4 > 0x7fffffffL) return hipErrorInvalidValue;
     if (a.img && (ks != 3 || nt != 2 || a.Cin != 64 || a.mw != 32)) return hipErrorInvalidValue;
+    if (a.prec != 0) {
+        // reduced-precision modes exist for the 3x3 layers with 64-cout blocks (98 % of the arithmetic)
+        if (ks != 3 || nt != 2 || a.Cin % 16 || (a.prec != 1 && a.prec != 2)) return hipErrorInvalidValue;
+        if (a.prec == 1) {
+            if (a.img) hipLaunchKernelGGL((conv_bf16_kernel<2, true, 32, 3>), grid, block, 0, s, a);
+            else if (a.mw == 16) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 16, 3>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 3>), grid, block, 0, s, a);
+        } else {
+            if (a.img) hipLaunchKernelGGL((conv_bf16_kernel<2, true, 32, 1>), grid, block, 0, s, a);
+            else if (a.mw == 16) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 16, 1>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 1>), grid, block, 0, s, a);
+        }
+        return hipGetLastError();
+    }
     if (ks == 3 && nt == 2 && a.img) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, true>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2 && a.mw == 16) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8, false, 16>), grid, block, 0, s, a);
     else if (ks == 3 && nt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2, 8>), grid, block, 0, s, a);

@@ -20,13 +20,13 @@ FULL = [("full_480x640_s1_sparse.npz", "sparse"), ("full_480x640_s11_dense.npz",
 _ctx_cache = {}
 
 
-def get_ctx(pkg, W, H, max_num=500, batch=1):
-    key = (W, H, max_num, batch)
+def get_ctx(pkg, W, H, max_num=500, batch=1, precision=0):
+    key = (W, H, max_num, batch, precision)
     if key not in _ctx_cache:
         if len(_ctx_cache) > 6:
             k0 = next(iter(_ctx_cache))
             _ctx_cache.pop(k0).close()
-        _ctx_cache[key] = pkg.Context(pkg.default_config(W, H, max_batch=batch, max_num=max_num))
+        _ctx_cache[key] = pkg.Context(pkg.default_config(W, H, max_batch=batch, max_num=max_num, precision=precision))
     return _ctx_cache[key]
 
 
@@ -592,3 +592,69 @@ def test_match_mutual_vs_oracle(pkg, orc):
     n, m12 = ctx.match_mutual(A, B, 0.8, c12, c21)
     on, om = orc.mutual_nn(A, B, 0.8, c12, c21)
     assert n == on and 5 < n < 150 and np.array_equal(m12, om)
+
+
+# ---- reduced-precision convolution modes (precision 1: bf16 hi/lo split, 2: plain bf16) ----
+
+@pytest.mark.parametrize("precision", [1, 2])
+def test_reduced_precision_cnn_vs_oracle(precision, pkg, onet, synth):
+    """The bf16 MFMA kernels against the oracle's statement of the same arithmetic (operands rounded to bf16 hi
+    (+ lo), exact products, fp32 accumulation).  Sizes cover the 8 x 32 and 16 x 16 tiles, ragged edges and the
+    fused first layer.  Tolerance: the two sides accumulate in different orders, so from the second layer on
+    their fp32 inputs differ by ~1e-6 relative, which is enough to flip the rounding of an operand's last kept
+    bit: 2^-17 (8e-6) of the value with the hi/lo split, 2^-8 (4e-3) with plain bf16.  Measured: 0.4-1.6e-5
+    (heat 2-3e-5) and 1.5-3.6e-3 (heat 7e-3) of the tensor's scale; a misplaced operand half shows as >= 1e-3
+    in the split mode."""
+    tol = {1: (4e-5, 1e-4), 2: (1.5e-2, 3e-2)}[precision]
+    for (H, W, seed, kind) in ((72, 104, 41, "sparse"), (128, 160, 42, "dense"), (240, 320, 43, "sparse")):
+        img = synth.make_frame(H, W, seed, 0, kind)
+        ctx = get_ctx(pkg, W, H, precision=precision)
+        ctx.inference([img])
+        ctx.detect_keypoints(1)
+        ctx.detect_lines(1)
+        t = onet.inference(img, precision)
+        for which, k in ((pkg.T_FEAT, "feat"), (pkg.T_JUNC, "junc"), (pkg.T_HEAT_RAW, "heat"), (pkg.T_DESCMAP, "desc")):
+            got, ref = ctx.read_tensor(which), nhwc(t[k])
+            err, scale = float(np.abs(got - ref).max()), float(np.abs(ref).max())
+            assert err <= tol[k == "heat"] * scale, (H, W, k, err, scale)
+
+
+def _by_coord(r):
+    return {tuple(int(v) for v in p): i for i, p in enumerate(r["xy"])}
+
+
+@pytest.mark.parametrize("name,kind", FULL)
+def test_bf16_split_full_frame_vs_fp32_golden(name, kind, pkg, synth):
+    """precision 1 against the fp32 goldens of the reference nets: descriptors within the 1e-3 bar at every key
+    point both lists hold, key-point sets equal except where scores are within the split's error (2e-4) of a
+    competitor or of the cap, the edge sets nearly equal (a few heat pixels sit within 1e-3 of a threshold)."""
+    g = golden(name)
+    H, W, seed, maxnum = [int(v) for v in g["meta"]]
+    ctx = get_ctx(pkg, W, H, maxnum, precision=1)
+    for t in (0, 1):
+        r = ctx.extract(synth.make_frame(H, W, seed, t, kind))
+        assert float(np.abs(ctx.read_tensor(pkg.T_SCORE)[::4, ::4] - g[f"score_sub_{t}"]).max()) < 3e-4
+        a, b = _by_coord(r), {tuple(int(v) for v in p): i for i, p in enumerate(g[f"kp_xy_{t}"])}
+        common = sorted(set(a) & set(b))
+        assert len(common) >= 0.98 * len(b), (len(common), len(b))
+        ia, ib = [a[p] for p in common], [b[p] for p in common]
+        assert float(np.linalg.norm(r["desc"][ia] - g[f"kp_desc_{t}"][ib], axis=1).max()) < 1e-3
+        assert float(np.abs(r["score"][ia] - g[f"kp_score_{t}"][ib]).max()) < 3e-4
+        ea, eb = edge_coord_set(r["edge_idx"], r["xy"]), edge_coord_set(g[f"edge_idx_{t}"], g[f"kp_xy_{t}"])
+        assert len(ea ^ eb) <= max(4, 0.05 * len(eb)), (len(ea ^ eb), len(eb))
+
+
+def test_plain_bf16_deviation_report(pkg, synth, capsys):
+    """precision 2 is outside the parity bar by construction; this records how far (and that the path runs)."""
+    g = golden(FULL[0][0])
+    H, W, seed, maxnum = [int(v) for v in g["meta"]]
+    ctx = get_ctx(pkg, W, H, maxnum, precision=2)
+    r = ctx.extract(synth.make_frame(H, W, seed, 0, FULL[0][1]))
+    a, b = _by_coord(r), {tuple(int(v) for v in p): i for i, p in enumerate(g["kp_xy_0"])}
+    common = sorted(set(a) & set(b))
+    dd = np.linalg.norm(r["desc"][[a[p] for p in common]] - g["kp_desc_0"][[b[p] for p in common]], axis=1)
+    with capsys.disabled():
+        print(f"\nplain bf16 vs fp32: {len(common)}/{len(b)} key points in common, descriptor L2 max {dd.max():.3e} "
+              f"mean {dd.mean():.3e}")
+    assert len(common) >= 0.8 * len(b)
+    assert float(dd.max()) < 0.5
