@@ -37,11 +37,18 @@ struct Inc {
 
 constexpr int kBuckets = 16;
 
+// The lines incident to one point, grouped by direction sector inside ONE contiguous array (sector s =
+// e[off[s] .. off[s+1])), so that a walk over neighbouring sectors reads a few consecutive cache lines.
+struct PointLists {
+    uint16_t off[kBuckets + 1];
+    std::vector<Inc> e;
+};
+
 // Per-frame scratch that survives between calls so the tail allocates nothing in steady state.
 struct TailScratch {
     std::vector<Cand> lines;
     std::vector<uint8_t> bad;  // isBad per line
-    std::vector<std::vector<Inc>> conn;
+    std::vector<PointLists> pts;
     std::vector<std::vector<uint32_t>> conn2;
 };
 
@@ -58,9 +65,12 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
     std::vector<uint8_t>& bad = ts.bad;
     lines.clear();
     bad.clear();
-    if (ts.conn.size() < (size_t)n * kBuckets) { ts.conn.resize((size_t)n * kBuckets); ts.conn2.resize(n); }
-    std::vector<std::vector<Inc>>& conn = ts.conn;
-    for (size_t p = 0; p < (size_t)n * kBuckets; p++) conn[p].clear();
+    if (ts.pts.size() < (size_t)n) { ts.pts.resize(n); ts.conn2.resize(n); }
+    std::vector<PointLists>& pts = ts.pts;
+    for (int p = 0; p < n; p++) {
+        pts[p].e.clear();
+        for (int t = 0; t <= kBuckets; t++) pts[p].off[t] = 0;
+    }
     const float distTh = cfg.line_dist_thresh;
     // Incidence lists are split into kBuckets direction sectors per point.  Only lines within 0.2*pi of
     // the new direction can pass the angle gate of :326/:348, so the walk visits the sectors that can
@@ -71,33 +81,69 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
         int b = (int)((dir + (float)kPi) * bscale);
         return b < 0 ? 0 : (b >= kBuckets ? kBuckets - 1 : b);
     };
+    auto insert = [&](uint32_t p, float dir, float dist, uint32_t lid) {
+        PointLists& pl = pts[p];
+        const int sct = sector(dir);
+        pl.e.insert(pl.e.begin() + pl.off[sct + 1], Inc{dir, dist, lid});
+        for (int t = sct + 1; t <= kBuckets; t++) pl.off[t]++;
+    };
     auto overlap = [&](uint32_t a, float dirAB, float dNew) -> bool {  // :316-335 / :338-357
-        bool isOverlap = false;
+        PointLists& pl = pts[a];
+        if (pl.e.empty()) return false;
+        bool isOverlap = false, sawDead = false;
         const float slack = 0.2f * (float)kPi + 1e-3f;
-        const int b0 = (int)std::floor((dirAB - slack + (float)kPi) * bscale);
-        int b1 = (int)std::floor((dirAB + slack + (float)kPi) * bscale);
+        // floor() of values in (-2, kBuckets + 2) by truncation of the value shifted to be positive
+        const int b0 = (int)((dirAB - slack + (float)kPi) * bscale + 8.f) - 8;
+        int b1 = (int)((dirAB + slack + (float)kPi) * bscale + 8.f) - 8;
         if (b1 - b0 >= kBuckets) b1 = b0 + kBuckets - 1;
-        for (int bb = b0; bb <= b1; bb++) {
-            std::vector<Inc>& lst = conn[(size_t)a * kBuckets + ((bb % kBuckets) + kBuckets) % kBuckets];
-            // Dead lines are skipped by the reference and never come back to life, so they are dropped
-            // from the list while walking it (keeps the walk proportional to the live degree).
-            size_t keep = 0;
-            const size_t len = lst.size();
-            for (size_t rd = 0; rd < len; rd++) {
-                const Inc e = lst[rd];
-                if (bad[e.lid]) continue;
-                lst[keep++] = e;
+        auto walk = [&](int s0, int s1) {  // sectors s0..s1, both inside [0, kBuckets)
+            const Inc* q = pl.e.data() + pl.off[s0];
+            const Inc* const end = pl.e.data() + pl.off[s1 + 1];
+            for (; q < end; ++q) {
+                const Inc e = *q;
+                if (bad[e.lid]) { sawDead = true; continue; }
                 float ad = dirAB - e.dir;
                 if (ad < -kPi) ad = (float)(ad + k2Pi);
                 if (ad > kPi) ad = (float)(ad - k2Pi);
                 ad = std::fabs(ad);
                 if (ad > 0.2 * kPi) continue;
                 const float dOld = e.dist;
-                const float s = std::sin(ad);
-                if (dNew <= dOld && dNew * s < distTh) bad[e.lid] = 1;
-                if (dOld < dNew && dOld * s < distTh) isOverlap = true;
+                // Both tests of the reference ask whether (shorter length) * sin(ad) < distTh.  For 0 <= x <= 0.2*pi
+                // the sine lies between x - x^3/6 (>= 0.934 x) and x; when the product with a bound is on the same
+                // side of the threshold by more than every rounding involved (the float sine, the float product:
+                // < 3e-7 relative) the answer is known without evaluating the sine.
+                const float dMin = dNew <= dOld ? dNew : dOld;
+                const float pa = dMin * ad;
+                bool close;
+                if (pa * 0.93f > distTh) close = false;
+                else if (pa * 1.00001f < distTh) close = true;
+                else {
+                    const double x = ad, x2 = x * x, lo = x - x * x2 * (1.0 / 6.0), hi = lo + x * x2 * x2 * (1.0 / 120.0);
+                    if ((double)dMin * hi * (1.0 + 1e-6) < (double)distTh) close = true;
+                    else if ((double)dMin * lo * (1.0 - 1e-6) > (double)distTh) close = false;
+                    else close = dMin * std::sin(ad) < distTh;
+                }
+                if (!close) continue;
+                if (dNew <= dOld) bad[e.lid] = 1;
+                else isOverlap = true;
             }
-            lst.resize(keep);
+        };
+        // dirAB lies in [-pi, pi], so b1 >= 0 and b0 < kBuckets: at most one end of the range wraps
+        if (b0 < 0) { walk(b0 + kBuckets, kBuckets - 1); walk(0, b1); }
+        else if (b1 >= kBuckets) { walk(b0, kBuckets - 1); walk(0, b1 - kBuckets); }
+        else walk(b0, b1);
+        if (sawDead) {
+            // Dead lines are skipped by the reference and never come back to life: drop them from this point's
+            // list (keeps the walks proportional to the live degree).
+            uint16_t w = 0;
+            for (int sct = 0; sct < kBuckets; sct++) {
+                const uint16_t from = pl.off[sct], to = pl.off[sct + 1];
+                pl.off[sct] = w;
+                for (uint16_t r = from; r < to; r++)
+                    if (!bad[pl.e[r].lid]) pl.e[w++] = pl.e[r];
+            }
+            pl.off[kBuckets] = w;
+            pl.e.resize(w);
         }
         return isOverlap;
     };
@@ -118,8 +164,8 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
         const uint32_t lid = (uint32_t)lines.size();
         lines.push_back(cd);
         bad.push_back(0);
-        conn[(size_t)cd.i * kBuckets + sector(cd.dir_ij)].push_back(Inc{cd.dir_ij, cd.dist, lid});
-        conn[(size_t)cd.j * kBuckets + sector(cd.dir_ji)].push_back(Inc{cd.dir_ji, cd.dist, lid});
+        insert(cd.i, cd.dir_ij, cd.dist, lid);
+        insert(cd.j, cd.dir_ji, cd.dist, lid);
     }
     std::vector<std::vector<uint32_t>>& c2 = ts.conn2;
     for (int p = 0; p < n; p++) c2[p].clear();

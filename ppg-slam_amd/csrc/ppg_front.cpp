@@ -5,11 +5,16 @@
 // as the reference's -O3 build without FMA code generation does.
 #include "../../include/ppgfront.h"
 #include "ppg_kernels.h"
+#include "host_pool.h"
 #include "lines_tail.h"
 
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -133,6 +138,7 @@ struct ppg_ctx {
     int cur = 0;  // slot the alias pointers above refer to
     std::vector<TailScratch> tails;
     int host_threads = 1;
+    HostPool* pool = nullptr;  // host_threads - 1 workers, created with the first batch that needs them
     bool skip_score = false, skip_heat = false, skip_refine = false;
     bool unfused_conv1a = false;
     int last_n = 0;
@@ -632,6 +638,8 @@ const char* ppg_last_error(const ppg_ctx* c) { return c ? c->err.c_str() : g_err
 
 void ppg_destroy(ppg_ctx* c) {
     if (!c) return;
+    delete c->pool;
+    c->pool = nullptr;
     (void)hipSetDevice(c->cfg.device_id);
     for (Lane& l : c->lane)
         if (l.stream) (void)hipStreamSynchronize(l.stream);
@@ -1028,12 +1036,8 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
     if (nthreads == 1) {
         for (int b = 0; b < n; b++) do_frame(b);
     } else {
-        std::vector<std::thread> pool;
-        pool.reserve(nthreads - 1);
-        for (int t = 1; t < nthreads; t++)
-            pool.emplace_back([&, t]() { for (int b = t; b < n; b += nthreads) do_frame(b); });
-        for (int b = 0; b < n; b += nthreads) do_frame(b);
-        for (auto& th : pool) th.join();
+        if (!c->pool) c->pool = new HostPool(c->host_threads - 1);
+        c->pool->run(n, do_frame);
     }
     if (c->prof) {
         c->prof_ms[PPG_PROF_HOST_TAIL] += now_ms() - t_tail0;
