@@ -1,5 +1,5 @@
 // Isolated timing of the convolution kernel on the layer shapes of the 640x480 front-end (batch 16).
-// Usage: conv_bench <0 zeros | 1 random | 2 small positive | 3 denormal-range inputs> [batch]
+// Usage: conv_bench <0 zeros | 1 random | 2 small positive | 3 denormal-range inputs> [batch] [precision 0|1|2]
 #include "../../ppg-slam_amd/csrc/ppg_kernels.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +30,7 @@ __global__ void fill_rand8(uint8_t* p, size_t n) {
 struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, nbuf, ks = 3; };
 int main(int argc, char** argv) {
     const int B = argc > 2 ? atoi(argv[2]) : 16;
+    const int prec = argc > 3 ? atoi(argv[3]) : 0;
     std::vector<L> ls = {
         {"conv1b fused pool", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 1},
         {"conv1b fused pool nbuf2", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 2},
@@ -69,7 +70,9 @@ int main(int argc, char** argv) {
     long long* dclk; hipMalloc(&dclk, 16); long long hclk[2];
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (const L& l : ls) {
+        if (prec && (l.ks != 3 || l.nt != 2)) continue;
         ConvArgs a{};
+        a.prec = prec;
         a.in = din; a.wpk = dw; a.B = B; a.H = l.H; a.W = l.W; a.Cin = l.Cin;
         if (l.fused) { a.img = dimg; a.w1a = dw; a.b1a = dbias; }
         const int tw = l.mw, th = 256 / l.mw;
