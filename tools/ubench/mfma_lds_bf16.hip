@@ -1,7 +1,8 @@
 // Inner loop of the bf16 hi/lo-split 3x3 convolution kernel rebuilt bottom-up: per chunk 9 taps x (8 ds_read_b128 +
 // 12 v_mfma_f32_32x32x16_bf16), long-lived work-groups, two per CU.  MODE bits: 1 two barriers per chunk, 2 stash
 // 15 x ds_write_b128 between them, 4 the stashed registers come from 15 buffer loads issued before the MFMAs,
-// 8 the bf16 split arithmetic on the staged input registers, 16 operand reads issued one tap ahead.
+// 8 the bf16 split arithmetic on the staged input registers, 16 operand reads issued one tap ahead, 32 six of the
+// loads gather 16-byte pieces at a 256-byte stride (the input tile of a 64-channel layer) instead of streaming.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -66,8 +67,11 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* src, int ch
     for (int c = 0; c < chunks; c++) {
         if (MODE & 4) {
 #pragma unroll
-            for (int k2 = 0; k2 < 15; k2++)
-                st[k2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 256 * k2) * 16, ((c * 7 + blockIdx.x) & 511) * 65536, 0));
+            for (int k2 = 0; k2 < 15; k2++) {
+                unsigned off = (tid + 256 * k2) * 16;
+                if ((MODE & 32) && k2 < 6) off = ((tid + 256 * (k2 >> 1)) >> 1) * 256 + (tid & 1) * 32 + (k2 & 1) * 16 + (c & 3) * 64;
+                st[k2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, ((c * 7 + blockIdx.x) & 255) * 131072, 0));
+            }
         }
         if (MODE & 16) {
             Ops ops[2];
@@ -146,5 +150,9 @@ int main() {
     run<23>(d, src, 2000, dclk);
     run<15>(d, src, 2000, dclk);
     run<31>(d, src, 2000, dclk);
+    run<47>(d, src, 2000, dclk);
+    run<63>(d, src, 2000, dclk);
+    run<15>(d, src, 8, dclk);
+    run<47>(d, src, 8, dclk);
     return 0;
 }
