@@ -957,12 +957,11 @@ static int enqueue_d2h(ppg_ctx* c, int si, int n) {
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_un, sl.kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_out, sl.kp_out, (size_t)M * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_desc, sl.desc, sizeof(float) * 256 * M * n, hipMemcpyDeviceToHost, s));
-    for (int b = 0; b < n; b++) {
-        HIPCHK(c, hipMemcpyAsync(sl.h_cand_ij + (size_t)b * c->cand_cap, sl.cand_ij + (size_t)b * c->cand_cap,
-                                 sizeof(uint32_t) * c->cand_fast, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_cand_sc + (size_t)b * c->cand_cap * 2, sl.cand_sc + (size_t)b * c->cand_cap * 2,
-                                 sizeof(float) * 2 * c->cand_fast, hipMemcpyDeviceToHost, s));
-    }
+    // the first cand_fast line candidates of every frame: one strided copy per array instead of one per frame
+    HIPCHK(c, hipMemcpy2DAsync(sl.h_cand_ij, sizeof(uint32_t) * c->cand_cap, sl.cand_ij, sizeof(uint32_t) * c->cand_cap,
+                               sizeof(uint32_t) * c->cand_fast, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(sl.h_cand_sc, sizeof(float) * 2 * c->cand_cap, sl.cand_sc, sizeof(float) * 2 * c->cand_cap,
+                               sizeof(float) * 2 * c->cand_fast, n, hipMemcpyDeviceToHost, s));
     if (sl.matched) {
         HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, s));
