@@ -56,6 +56,45 @@ def test_sharding_and_barrier_two_ranks():
         assert r0 == r1 == [0, 0, 1, 2, 3]
 
 
+def _stereo_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    load_pkg()
+    streams = importlib.import_module("ppg_slam_amd.streams")
+    ex = streams.StereoExchange(dist, "cpu", max_num=64)
+    got = []
+    for frame in range(3):  # ragged counts, the second call smaller than the first
+        n = (40, 7, 64)[frame] if rank == 0 else (0, 33, 5)[frame]
+        g = torch.Generator().manual_seed(100 * rank + frame)
+        mine = torch.rand(64, 256, generator=g)
+        theirs, m = ex.swap(mine, n)
+        got.append((m, theirs.clone()))
+    q.put((rank, [(m, t.numpy()) for m, t in got]))
+    dist.destroy_process_group()
+
+
+def test_stereo_exchange_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_stereo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts = {0: (40, 7, 64), 1: (0, 33, 5)}
+    for rank in (0, 1):
+        other = rank ^ 1
+        for frame, (m, t) in enumerate(res[rank]):
+            assert m == counts[other][frame]
+            g = torch.Generator().manual_seed(100 * other + frame)
+            want = torch.rand(64, 256, generator=g)[:m].numpy()
+            assert t.shape == (m, 256) and (t == want).all()
+
+
 def test_shard_streams_covers_everything():
     load_pkg()
     streams = importlib.import_module("ppg_slam_amd.streams")
