@@ -35,13 +35,21 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
     const bool bn = G.alpha != nullptr;
     const bool vec = (G.Cout & 3) == 0;  // rows of the output are 16-byte aligned
     const int Cps = G.Cout >> 2;
+    // All bias vectors are fetched before the first store: a store to `out` may alias them as far as the compiler
+    // knows, so loads left inside the loops would each wait out a full memory latency behind the stores before them.
+    // (The bias arrays are padded to whole cout blocks.)
+    f32x4 biasv[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) biasv[n][j] = *(const f32x4*)(G.bias + cb + n * 32 + 8 * j + 4 * lh);
 #pragma unroll
     for (int n = 0; n < NT; n++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int co = cb + n * 32 + 8 * j + 4 * lh;  // first of the four couts
             if (co >= G.Cout) continue;
-            const f32x4 bias = *(const f32x4*)(G.bias + co);
+            const f32x4 bias = biasv[n][j];
             f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
             if (bn) { al = *(const f32x4*)(G.alpha + co); be = *(const f32x4*)(G.beta + co); }
             if (G.mode == CONV_POOL2) {
