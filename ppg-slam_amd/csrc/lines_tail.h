@@ -28,19 +28,22 @@ struct Cand {
 };
 
 // One entry of a point's incidence list: what the overlap test needs about a line, stored inline so
-// that the walk over a list touches contiguous memory only.
+// that the walk over a list touches the point's own small array only.
 struct Inc {
     float dir;     // direction of the line seen from this point
     float dist;
     uint32_t lid;  // index into TailScratch::lines
+    int32_t next;  // next entry of the same direction sector, -1 = end
 };
 
-constexpr int kBuckets = 16;
+constexpr int kBuckets = 32;
 
-// The lines incident to one point, grouped by direction sector inside ONE contiguous array (sector s =
-// e[off[s] .. off[s+1])), so that a walk over neighbouring sectors reads a few consecutive cache lines.
+// The lines incident to one point: entries in arrival order in ONE contiguous array, chained per direction
+// sector (head[s] = newest entry of sector s), so that listing a line is an append and a walk over
+// neighbouring sectors stays inside a few cache lines.
 struct PointLists {
-    uint16_t off[kBuckets + 1];
+    int32_t head[kBuckets];
+    float dmin;  // lower bound of the length of every line ever listed here
     std::vector<Inc> e;
 };
 
@@ -69,7 +72,8 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
     std::vector<PointLists>& pts = ts.pts;
     for (int p = 0; p < n; p++) {
         pts[p].e.clear();
-        for (int t = 0; t <= kBuckets; t++) pts[p].off[t] = 0;
+        pts[p].dmin = 3.0e38f;
+        for (int t = 0; t < kBuckets; t++) pts[p].head[t] = -1;
     }
     const float distTh = cfg.line_dist_thresh;
     // Incidence lists are split into kBuckets direction sectors per point.  Only lines within 0.2*pi of
@@ -84,24 +88,36 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
     auto insert = [&](uint32_t p, float dir, float dist, uint32_t lid) {
         PointLists& pl = pts[p];
         const int sct = sector(dir);
-        pl.e.insert(pl.e.begin() + pl.off[sct + 1], Inc{dir, dist, lid});
-        for (int t = sct + 1; t <= kBuckets; t++) pl.off[t]++;
+        pl.e.push_back(Inc{dir, dist, lid, pl.head[sct]});
+        pl.head[sct] = (int32_t)pl.e.size() - 1;
+        if (dist < pl.dmin) pl.dmin = dist;
     };
     auto overlap = [&](uint32_t a, float dirAB, float dNew) -> bool {  // :316-335 / :338-357
         PointLists& pl = pts[a];
         if (pl.e.empty()) return false;
-        bool isOverlap = false, sawDead = false;
-        const float slack = 0.2f * (float)kPi + 1e-3f;
+        bool isOverlap = false;
+        // A listed line matters only if it passes the angle gate AND (shorter length) * sin(angle) < distTh.  The
+        // shorter length is at least dLow = min(dNew, shortest line ever listed here), and sin(x) >= x * 2/pi on
+        // [0, pi/2], so lines further than distTh / dLow * pi/2 from the new direction cannot matter: the walk is
+        // narrowed to that angle (plus slack for rounding) when it is smaller than the gate.
+        float slack = 0.2f * (float)kPi + 1e-3f;
+        const float dLow = dNew < pl.dmin ? dNew : pl.dmin;
+        const float narrow = distTh / dLow * 1.5708f + 2e-3f;
+        if (narrow < slack) slack = narrow;
         // floor() of values in (-2, kBuckets + 2) by truncation of the value shifted to be positive
         const int b0 = (int)((dirAB - slack + (float)kPi) * bscale + 8.f) - 8;
         int b1 = (int)((dirAB + slack + (float)kPi) * bscale + 8.f) - 8;
         if (b1 - b0 >= kBuckets) b1 = b0 + kBuckets - 1;
         auto walk = [&](int s0, int s1) {  // sectors s0..s1, both inside [0, kBuckets)
-            const Inc* q = pl.e.data() + pl.off[s0];
-            const Inc* const end = pl.e.data() + pl.off[s1 + 1];
-            for (; q < end; ++q) {
-                const Inc e = *q;
-                if (bad[e.lid]) { sawDead = true; continue; }
+          for (int sct = s0; sct <= s1; sct++) {
+            int32_t* link = &pl.head[sct];
+            while (*link >= 0) {
+                Inc& ent = pl.e[*link];
+                // Dead lines are skipped by the reference and never come back to life: unlink them while walking
+                // (keeps the walks proportional to the live degree).
+                if (bad[ent.lid]) { *link = ent.next; continue; }
+                link = &ent.next;
+                const Inc e = ent;
                 float ad = dirAB - e.dir;
                 if (ad < -kPi) ad = (float)(ad + k2Pi);
                 if (ad > kPi) ad = (float)(ad - k2Pi);
@@ -127,27 +143,28 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
                 if (dNew <= dOld) bad[e.lid] = 1;
                 else isOverlap = true;
             }
+          }
         };
         // dirAB lies in [-pi, pi], so b1 >= 0 and b0 < kBuckets: at most one end of the range wraps
         if (b0 < 0) { walk(b0 + kBuckets, kBuckets - 1); walk(0, b1); }
         else if (b1 >= kBuckets) { walk(b0, kBuckets - 1); walk(0, b1 - kBuckets); }
         else walk(b0, b1);
-        if (sawDead) {
-            // Dead lines are skipped by the reference and never come back to life: drop them from this point's
-            // list (keeps the walks proportional to the live degree).
-            uint16_t w = 0;
-            for (int sct = 0; sct < kBuckets; sct++) {
-                const uint16_t from = pl.off[sct], to = pl.off[sct + 1];
-                pl.off[sct] = w;
-                for (uint16_t r = from; r < to; r++)
-                    if (!bad[pl.e[r].lid]) pl.e[w++] = pl.e[r];
-            }
-            pl.off[kBuckets] = w;
-            pl.e.resize(w);
-        }
         return isOverlap;
     };
     for (int k = 0; k < nc; k++) {
+        // The second end point of a candidate is a random point: its lists are fetched ahead of their use.
+        if (k + 8 < nc) {
+            const char* ph = (const char*)&pts[ij[k + 8] & 0xFFFFu];
+            __builtin_prefetch(ph);
+            __builtin_prefetch(ph + 64);
+            __builtin_prefetch(ph + 128);
+        }
+        if (k + 4 < nc) {
+            const PointLists& pn = pts[ij[k + 4] & 0xFFFFu];
+            const char* pe = (const char*)pn.e.data();
+            const size_t bytes = pn.e.size() * sizeof(Inc);
+            for (size_t o = 0; o < bytes && o < 512; o += 64) __builtin_prefetch(pe + o);
+        }
         Cand cd;
         cd.i = ij[k] >> 16; cd.j = ij[k] & 0xFFFFu;
         float vx = un[2 * cd.j] - un[2 * cd.i], vy = un[2 * cd.j + 1] - un[2 * cd.i + 1];

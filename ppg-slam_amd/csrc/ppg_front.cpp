@@ -138,6 +138,8 @@ struct ppg_ctx {
     int cur = 0;  // slot the alias pointers above refer to
     std::vector<TailScratch> tails;
     int host_threads = 1;
+    const char* dump_tail = nullptr;
+    bool dump_tail_done = false;
     HostPool* pool = nullptr;  // host_threads - 1 workers, created with the first batch that needs them
     bool skip_score = false, skip_heat = false, skip_refine = false;
     bool unfused_conv1a = false;
@@ -697,6 +699,7 @@ static int create_impl(ppg_ctx* c) {
         c->unfused_conv1a = u && atoi(u) != 0;
         const char* nl = getenv("PPG_CNN_LANES");
         if (nl && atoi(nl) == 2) c->nlanes = 2;
+        c->dump_tail = getenv("PPG_DUMP_TAIL");
         const char* e = getenv("PPG_HOST_THREADS");
         int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         c->host_threads = std::max(1, std::min(t, 64));
@@ -996,6 +999,19 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
     if (more) HIPCHK(c, hipStreamSynchronize(s));
     if (c->prof) prof_resolve(c);
     for (int b = 0; b < n; b++) sl.nkp[b] = sl.h_counters[b * 8 + 3];
+    if (c->dump_tail && !c->dump_tail_done && sl.h_counters[3] > 0 && sl.h_counters[2] > 0) {
+        // debugging aid (PPG_DUMP_TAIL=<file>): the first frame's input of lines_tail(), in the format that
+        // tools/bench_tail.cpp reads
+        c->dump_tail_done = true;
+        if (FILE* f = fopen(c->dump_tail, "wb")) {
+            const int32_t hdr[2] = {sl.h_counters[3], sl.h_counters[2]};
+            fwrite(hdr, 4, 2, f);
+            fwrite(sl.h_kp_un, 4, (size_t)2 * hdr[0], f);
+            fwrite(sl.h_cand_ij, 4, (size_t)hdr[1], f);
+            fwrite(sl.h_cand_sc, 4, (size_t)2 * hdr[1], f);
+            fclose(f);
+        }
+    }
     const double t_tail0 = now_ms();
     std::vector<double> frame_ms(n, 0.0);
     auto do_frame = [&](int b) {
