@@ -1252,13 +1252,22 @@ __global__ __launch_bounds__(1024) void line_scan_kernel(LineArgs a) {
     if (tid == 1023) cnt[2] = part[1023];
 }
 
+// Sixteen lanes per candidate: the samples of a line are evaluated sixteen at a time (the loads and the bilinear
+// terms, which is where the time goes), then added to the running sum one by one in sample order — the order of
+// the reference's loop, which fixes the rounding of the score.
 __global__ __launch_bounds__(256) void line_score_kernel(LineArgs a) {
     const int b = blockIdx.y;
     const int* cnt = a.counters + b * 8;
     const int nc = min(cnt[2], a.cand_cap);
     const float* un = a.kp_un + (size_t)b * a.max_num * 2;
     const float* heat = a.heat + (size_t)b * a.H * a.W;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < nc; k += gridDim.x * 256) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15;
+    const int groups = gridDim.x * 16;
+    // every lane of a wave runs the same number of rounds (wave-wide shuffles inside)
+    for (int kw = (blockIdx.x * 256 + (threadIdx.x & ~63)) >> 4; kw < nc; kw += groups) {  // kw: the wave's first candidate
+        const int k0 = kw + g;
+        const bool live = k0 < nc;
+        const int k = live ? k0 : 0;
         const uint32_t ij = a.cand_ij[(size_t)b * a.cand_cap + k];
         const int i = ij >> 16, j = ij & 0xFFFF;
         // ps = start (i), pe = end (j)
@@ -1266,34 +1275,51 @@ __global__ __launch_bounds__(256) void line_score_kernel(LineArgs a) {
         const float dx = psx - pex, dy = psy - pey;
         const float dist = __fsqrt_rn(dx * dx + dy * dy);
         const int lenLevel = (int)((double)(dist * a.inv_scale) * 4.0);
-        const int segNum = (int)(dist * kInvSampleGap[lenLevel < 0 ? 0 : (lenLevel > 3 ? 3 : lenLevel)]);
+        const int segNum = live ? (int)(dist * kInvSampleGap[lenLevel < 0 ? 0 : (lenLevel > 3 ? 3 : lenLevel)]) : 0;
         const float step = (float)(1.0 / (double)(float)segNum);
         int inl = 0;
         float sum = 0.f;
-        for (int t = 1; t < segNum; t++) {
-            const float sx = psx * step * (float)t + pex * step * (float)(segNum - t);
-            const float sy = psy * step * (float)t + pey * step * (float)(segNum - t);
-            const int px = (int)((double)sx + 0.5), py = (int)((double)sy + 0.5);
-            // bilinearInterpolation, PPGExtractor.cpp:580-589.  Its four taps are two 8-byte loads, and the
-            // rounded sample position of the inlier test is one of them (sx, sy >= 0 for in-image end points).
-            const int x1 = (int)sx, x2 = x1 + 1, y1 = (int)sy, y2 = y1 + 1;
-            const f32x2u r1 = *(const f32x2u*)(heat + (size_t)y1 * a.W + x1);
-            const f32x2u r2 = *(const f32x2u*)(heat + (size_t)y2 * a.W + x1);
-            float hp;
-            if ((px == x1 || px == x2) && (py == y1 || py == y2)) {
-                const f32x2u r = py == y1 ? r1 : r2;
-                hp = px == x1 ? r[0] : r[1];
-            } else {
-                hp = heat_at(heat, a.W, py, px);
+        int segMax = max(segNum, __shfl_xor(segNum, 16));
+        segMax = max(segMax, __shfl_xor(segMax, 32));
+        for (int base = 1; base < segMax; base += 16) {
+            const int t = base + gl;
+            float val = 0.f;
+            bool hit = false;
+            if (t < segNum) {
+                const float sx = psx * step * (float)t + pex * step * (float)(segNum - t);
+                const float sy = psy * step * (float)t + pey * step * (float)(segNum - t);
+                const int px = (int)((double)sx + 0.5), py = (int)((double)sy + 0.5);
+                // bilinearInterpolation, PPGExtractor.cpp:580-589.  Its four taps are two 8-byte loads, and the
+                // rounded sample position of the inlier test is one of them (sx, sy >= 0 for in-image end points).
+                const int x1 = (int)sx, x2 = x1 + 1, y1 = (int)sy, y2 = y1 + 1;
+                const f32x2u r1 = *(const f32x2u*)(heat + (size_t)y1 * a.W + x1);
+                const f32x2u r2 = *(const f32x2u*)(heat + (size_t)y2 * a.W + x1);
+                float hp;
+                if ((px == x1 || px == x2) && (py == y1 || py == y2)) {
+                    const f32x2u r = py == y1 ? r1 : r2;
+                    hp = px == x1 ? r[0] : r[1];
+                } else {
+                    hp = heat_at(heat, a.W, py, px);
+                }
+                hit = hp > a.heat_thresh;
+                const float d1 = ((float)x2 - sx) * r1[0] + (sx - (float)x1) * r1[1];
+                const float d2 = ((float)x2 - sx) * r2[0] + (sx - (float)x1) * r2[1];
+                val = ((float)y2 - sy) * d1 + (sy - (float)y1) * d2;
             }
-            if (hp > a.heat_thresh) inl++;
-            const float d1 = ((float)x2 - sx) * r1[0] + (sx - (float)x1) * r1[1];
-            const float d2 = ((float)x2 - sx) * r2[0] + (sx - (float)x1) * r2[1];
-            sum += ((float)y2 - sy) * d1 + (sy - (float)y1) * d2;
+            const unsigned long long hits = __ballot(hit);
+            inl += __popcll((hits >> (16 * g)) & 0xFFFFull);
+            const int left = segNum - base;  // samples of this line in the round
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float v = __shfl(val, 16 * g + u);
+                if (u < left) sum += v;
+            }
         }
-        float* o = a.cand_sc + ((size_t)b * a.cand_cap + k) * 2;
-        o[0] = (float)inl / (float)(segNum - 1);
-        o[1] = sum / (float)(segNum - 1);
+        if (live && gl == 0) {
+            float* o = a.cand_sc + ((size_t)b * a.cand_cap + k) * 2;
+            o[0] = (float)inl / (float)(segNum - 1);
+            o[1] = sum / (float)(segNum - 1);
+        }
     }
 }
 
