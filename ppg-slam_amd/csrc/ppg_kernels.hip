@@ -1328,7 +1328,7 @@ hipError_t launch_line_candidates(const LineArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(line_pairs_kernel<false>, g1, dim3(256), 0, s, a);
     hipLaunchKernelGGL(line_scan_kernel, dim3(a.B), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(line_pairs_kernel<true>, g1, dim3(256), 0, s, a);
-    dim3 g2(64, a.B);
+    dim3 g2(1024, a.B);
     hipLaunchKernelGGL(line_score_kernel, g2, dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -8,7 +8,7 @@ spec = importlib.util.spec_from_file_location("ppg_slam_amd", os.path.join(root,
 pkg = importlib.util.module_from_spec(spec); sys.modules["ppg_slam_amd"] = pkg; spec.loader.exec_module(pkg)
 from ppg_slam_amd import synth
 H, W, B = int(os.environ.get("PB_H", 480)), int(os.environ.get("PB_W", 640)), int(os.environ.get("PB_B", 16))
-cfg = pkg.default_config(W, H); cfg.max_batch = B
+cfg = pkg.default_config(W, H, max_num=int(os.environ.get("PB_MAXNUM", 1024)), precision=int(os.environ.get("PB_PREC", 0))); cfg.max_batch = B
 ctx = pkg.Context(cfg)
 scenes = [synth.make_scene(H + 64, W + 128, 100 + s, "dense") for s in range(B)]
 prev = None
