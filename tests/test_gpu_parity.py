@@ -74,7 +74,7 @@ def test_stages_exact_on_injected_tensors(name, pkg, orc):
     assert np.array_equal(r["edge_score"], g["edge_score"], equal_nan=True)
     assert np.array_equal(r["conn_off"], g["conn_off"]) and np.array_equal(r["conn_idx"], g["conn_idx"])
     assert np.array_equal(r["coline_off"], g["coline_off"]) and np.array_equal(r["coline_pairs"], g["coline_pairs"])
-    # K11/K12 vs torch grid_sampler + normalize (north-star tolerance 1e-3)
+    # K11/K12 vs torch grid_sampler + normalize (required tolerance 1e-3)
     assert float(np.linalg.norm(r["desc"] - g["kp_desc"], axis=1).max()) < 1e-5
 
 

@@ -42,7 +42,7 @@ def test_post_processing_on_reference_tensors(name, orc):
     assert np.array_equal(ln["conn_idx"], g["conn_idx"])
     assert np.array_equal(ln["coline_pairs"], g["coline_pairs"])
     d = orc.gen_descriptors(cfg, g["desc"], kp["xy"])
-    # K11/K12 against torch.grid_sampler + F.normalize: 1e-3 is the north-star tolerance, we are ~1e-6
+    # K11/K12 against torch.grid_sampler + F.normalize: 1e-3 is the required descriptor tolerance, we are ~1e-6
     assert np.linalg.norm(d - g["kp_desc"], axis=1).max() < 1e-5
 
 
