@@ -126,6 +126,8 @@ struct ppg_ctx {
     uint32_t* cand_ij = nullptr;
     float* cand_sc = nullptr;
     int* row_cnt = nullptr;
+    unsigned long long* pair_mask = nullptr;
+    int mask_words = 0;
     // pinned host mirrors
     uint8_t* h_img = nullptr;
     int* h_counters = nullptr;
@@ -749,6 +751,8 @@ static int create_impl(ppg_ctx* c) {
     DA(kept, B * c->kept_cap);
     DA(kept_key, B * c->kept_cap);
     DA(row_cnt, B * (c->maxn + 1));
+    c->mask_words = (c->maxn + 255) / 256 * 4;
+    DA(pair_mask, B * (size_t)c->maxn * c->mask_words);
     DA(mCount, 4);
     HA(h_mcount, 4);
     for (Slot& sl : c->slot) {
@@ -928,7 +932,7 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
     }
     ppg::LineArgs la;
     la.heat = c->remapped ? c->remapped : c->refined; la.kp_un = c->kp_un; la.kp_out = c->kp_out; la.counters = c->counters;
-    la.row_cnt = c->row_cnt; la.cand_ij = c->cand_ij; la.cand_sc = c->cand_sc; la.cand_cap = c->cand_cap;
+    la.row_cnt = c->row_cnt; la.pair_mask = c->pair_mask; la.mask_words = c->mask_words; la.cand_ij = c->cand_ij; la.cand_sc = c->cand_sc; la.cand_cap = c->cand_cap;
     la.B = n; la.H = c->H; la.W = c->W; la.max_num = c->maxn;
     la.heat_thresh = c->cfg.line_heatmap_thresh;
     la.inv_scale = 1.0f / std::sqrt((float)(c->H * c->H + c->W * c->W));  // PPGExtractor.cpp:74

@@ -107,6 +107,8 @@ struct LineArgs {
     const uint8_t* kp_out;
     int* counters;        // [B][8]
     int* row_cnt;         // [B][max_num+1] work: survivors per row i, then their exclusive offsets
+    unsigned long long* pair_mask;  // [B][max_num][mask_words] work: probe results of row i, 64 pairs per word
+    int mask_words;       // >= ceil(max_num / 256) * 4
     uint32_t* cand_ij;    // [B][cand_cap] (i << 16 | j), ascending
     float* cand_sc;       // [B][cand_cap][2] inlier rate, mean bilinear heat
     int cand_cap;

@@ -1189,8 +1189,9 @@ __device__ inline bool line_probe(const LineArgs& a, const float* un, const uint
 }
 
 // Candidates leave the GPU already in the reference's loop order (i ascending, then j ascending):
-// pass 1 counts the survivors of every row i, a scan turns the counts into offsets, pass 2 repeats the
-// probe and writes each survivor at its ordered position (ballot prefix inside the work-group).
+// pass 1 probes every pair, keeps the wave ballots and counts the survivors of every row i, a scan turns the
+// counts into offsets, pass 2 reads the ballots back and writes each survivor at its ordered position (ballot
+// prefix inside the work-group).
 template <bool EMIT>
 __global__ __launch_bounds__(256) void line_pairs_kernel(LineArgs a) {
     __shared__ int wcnt[4];
@@ -1205,10 +1206,19 @@ __global__ __launch_bounds__(256) void line_pairs_kernel(LineArgs a) {
     int* rowcnt = a.row_cnt + (size_t)b * (a.max_num + 1);
     const bool row_ok = !out[i];
     int base = EMIT ? rowcnt[i] : 0;  // after the scan rowcnt[i] holds the exclusive offset
-    for (int j0 = i + 1; j0 < n; j0 += 256) {
+    unsigned long long* mrow = a.pair_mask + ((size_t)b * a.max_num + i) * a.mask_words + wave;
+    for (int j0 = i + 1; j0 < n; j0 += 256, mrow += 4) {
         const int j = j0 + tid;
-        const bool ok = row_ok && j < n && line_probe(a, un, out, heat, i, j);
-        const unsigned long long m = __ballot(ok);
+        bool ok;
+        unsigned long long m;
+        if (EMIT) {
+            m = *mrow;
+            ok = (m >> lane) & 1ull;
+        } else {
+            ok = row_ok && j < n && line_probe(a, un, out, heat, i, j);
+            m = __ballot(ok);
+            if (lane == 0) *mrow = m;
+        }
         if (lane == 0) wcnt[wave] = __popcll(m);
         __syncthreads();
         if (EMIT) {
