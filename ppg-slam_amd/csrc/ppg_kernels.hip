@@ -1175,7 +1175,8 @@ __constant__ float kInvSampleGap[4] = {0.3333f, 0.200f, 0.1427f, 0.1111f};  // P
 
 __device__ inline float heat_at(const float* heat, int W, int y, int x) { return heat[(size_t)y * W + x]; }
 
-// three-point heat probe of PPGExtractor.cpp:304-313
+// three-point heat probe of PPGExtractor.cpp:304-313 (most pairs fail the first lookup: the early exits save
+// more memory traffic than issuing the three gathers together saves latency)
 __device__ inline bool line_probe(const LineArgs& a, const float* un, const uint8_t* out, const float* heat, int i, int j) {
     if (out[j]) return false;
     const float ix = un[2 * i], iy = un[2 * i + 1], jx = un[2 * j], jy = un[2 * j + 1];
@@ -1205,32 +1206,34 @@ __global__ __launch_bounds__(256) void line_pairs_kernel(LineArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int* rowcnt = a.row_cnt + (size_t)b * (a.max_num + 1);
     const bool row_ok = !out[i];
-    int base = EMIT ? rowcnt[i] : 0;  // after the scan rowcnt[i] holds the exclusive offset
-    unsigned long long* mrow = a.pair_mask + ((size_t)b * a.max_num + i) * a.mask_words + wave;
-    for (int j0 = i + 1; j0 < n; j0 += 256, mrow += 4) {
-        const int j = j0 + tid;
-        bool ok;
-        unsigned long long m;
-        if (EMIT) {
-            m = *mrow;
-            ok = (m >> lane) & 1ull;
-        } else {
-            ok = row_ok && j < n && line_probe(a, un, out, heat, i, j);
-            m = __ballot(ok);
-            if (lane == 0) *mrow = m;
+    // ballots of the row: word 4*t + w = wave w of iteration t
+    unsigned long long* mrow = a.pair_mask + ((size_t)b * a.max_num + i) * a.mask_words;
+    if (!EMIT) {
+        int mine = 0;  // survivors seen by this wave
+        for (int j0 = i + 1; j0 < n; j0 += 256, mrow += 4) {
+            const int j = j0 + tid;
+            const bool ok = row_ok && j < n && line_probe(a, un, out, heat, i, j);
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) mrow[wave] = m;
+            mine += __popcll(m);
         }
-        if (lane == 0) wcnt[wave] = __popcll(m);
+        if (lane == 0) wcnt[wave] = mine;
         __syncthreads();
-        if (EMIT) {
-            int off = base;
-            for (int w = 0; w < wave; w++) off += wcnt[w];
-            off += __popcll(m & ((1ull << lane) - 1ull));
-            if (ok && off < a.cand_cap) a.cand_ij[(size_t)b * a.cand_cap + off] = ((uint32_t)i << 16) | (uint32_t)j;
+        if (tid == 0) rowcnt[i] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    } else {
+        int base = rowcnt[i];  // after the scan rowcnt[i] holds the exclusive offset
+        for (int j0 = i + 1; j0 < n; j0 += 256, mrow += 4) {
+            const unsigned long long m0 = mrow[0], m1 = mrow[1], m2 = mrow[2], m3 = mrow[3];
+            const unsigned long long m = wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3;
+            int off = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (wave > 0) off += __popcll(m0);
+            if (wave > 1) off += __popcll(m1);
+            if (wave > 2) off += __popcll(m2);
+            if (((m >> lane) & 1ull) && off < a.cand_cap)
+                a.cand_ij[(size_t)b * a.cand_cap + off] = ((uint32_t)i << 16) | (uint32_t)(j0 + tid);
+            base += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
         }
-        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
     }
-    if (!EMIT && tid == 0) rowcnt[i] = base;
 }
 
 // exclusive scan of the per-row counts of one frame (n <= 4096 rows), total -> counters[2]
