@@ -27,30 +27,25 @@ __global__ void fill_rand8(uint8_t* p, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; p[i] = (uint8_t)x; }
 }
-struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, nbuf, ks = 3; };
+struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, ks = 3; };
 int main(int argc, char** argv) {
     const int B = argc > 2 ? atoi(argv[2]) : 16;
     const int prec = argc > 3 ? atoi(argv[3]) : 0;
     std::vector<L> ls = {
-        {"conv1b fused pool", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 1},
-        {"conv1b fused pool nbuf2", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2, 2},
-        {"conv2a plain", 240, 320, 64, 64, CONV_PLAIN, 0, 32, 2, 1},
-        {"conv2b pool", 240, 320, 64, 64, CONV_POOL2, 0, 32, 2, 1},
-        {"conv3a plain", 120, 160, 64, 128, CONV_PLAIN, 0, 32, 2, 1},
-        {"conv3b pool", 120, 160, 128, 128, CONV_POOL2, 0, 32, 2, 1},
-        {"conv4a plain nt1", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 1, 2},
-        {"conv4a plain mw16", 60, 80, 128, 128, CONV_PLAIN, 0, 16, 2, 1},
-        {"conv4a plain nt1 nbuf1", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 1, 1},
-        {"conv4a plain mw32 nt2", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 2, 1},
-        {"h1 ps2-like plain", 120, 160, 64, 64, CONV_PLAIN, 0, 32, 2, 1},
-        {"h1 plain nt1 nbuf1", 120, 160, 64, 64, CONV_PLAIN, 0, 32, 1, 1},
-        {"h2 16->16 nt1 nbuf1", 240, 320, 16, 32, CONV_PLAIN, 0, 32, 1, 1},
-        {"h2 16->16 nt1 nbuf2", 240, 320, 16, 32, CONV_PLAIN, 0, 32, 1, 2},
-        {"heads 768 mw16", 60, 80, 128, 768, CONV_PLAIN, 0, 16, 2, 1},
-        {"db 1x1 256->256 nbuf2", 60, 80, 256, 256, CONV_PLAIN, 0, 32, 2, 2, 1},
-        {"db 1x1 256->256 nbuf1", 60, 80, 256, 256, CONV_PLAIN, 0, 32, 2, 1, 1},
-        {"pb 1x1 256->96 nbuf2", 60, 80, 256, 96, CONV_PLAIN, 0, 32, 1, 2, 1},
-        {"pb 1x1 256->96 nbuf1", 60, 80, 256, 96, CONV_PLAIN, 0, 32, 1, 1, 1},
+        {"conv1b fused pool", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2},
+        {"conv2a plain", 240, 320, 64, 64, CONV_PLAIN, 0, 32, 2},
+        {"conv2b pool", 240, 320, 64, 64, CONV_POOL2, 0, 32, 2},
+        {"conv3a plain", 120, 160, 64, 128, CONV_PLAIN, 0, 32, 2},
+        {"conv3b pool", 120, 160, 128, 128, CONV_POOL2, 0, 32, 2},
+        {"conv4a plain nt1", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 1},
+        {"conv4a plain mw16", 60, 80, 128, 128, CONV_PLAIN, 0, 16, 2},
+        {"conv4a plain mw32 nt2", 60, 80, 128, 128, CONV_PLAIN, 0, 32, 2},
+        {"h1 ps2-like plain", 120, 160, 64, 64, CONV_PLAIN, 0, 32, 2},
+        {"h1 plain nt1", 120, 160, 64, 64, CONV_PLAIN, 0, 32, 1},
+        {"h2 16->16 nt1", 240, 320, 16, 32, CONV_PLAIN, 0, 32, 1},
+        {"heads 768 mw16", 60, 80, 128, 768, CONV_PLAIN, 0, 16, 2},
+        {"db 1x1 256->256", 60, 80, 256, 256, CONV_PLAIN, 0, 32, 2, 1},
+        {"pb 1x1 256->96", 60, 80, 256, 96, CONV_PLAIN, 0, 32, 1, 1},
     };
     size_t maxin = (size_t)B * 480 * 640 * 64;
     float *din, *dout, *dw, *dbias; uint8_t* dimg;
