@@ -658,3 +658,17 @@ def test_plain_bf16_deviation_report(pkg, synth, capsys):
               f"mean {dd.mean():.3e}")
     assert len(common) >= 0.8 * len(b)
     assert float(dd.max()) < 0.5
+
+
+@pytest.mark.parametrize("precision", [1, 2])
+def test_reduced_precision_batch_equals_single(precision, pkg, synth):
+    """The reduced-precision kernels are deterministic and independent of the position in the batch: every frame of
+    a batch is bit-identical to the same frame extracted alone (same kernels, same order of operations)."""
+    H, W = 96, 128
+    imgs = [synth.make_frame(H, W, 50 + k, 0, "sparse" if k % 2 else "dense") for k in range(4)]
+    one = get_ctx(pkg, W, H, precision=precision)
+    singles = [one.extract(i) for i in imgs]
+    ctx = get_ctx(pkg, W, H, batch=4, precision=precision)
+    for r, s in zip(ctx.extract_batch(imgs), singles):
+        for k in ("xy", "score", "un", "out", "desc", "edge_idx", "conn_idx", "coline_pairs"):
+            assert np.array_equal(r[k], s[k], equal_nan=True), k
