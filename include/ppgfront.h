@@ -55,7 +55,11 @@ typedef struct ppg_config {
                                       into bf16 hi + lo and three products (hi*hi + hi*lo + lo*hi), fp32 accumulate:
                                       descriptors within 1e-3 of the fp32 path, key-point sets equal up to near-ties;
                                    2: the same layers with plain bf16 operands (outside the parity bar; for the
-                                      deviation report only).  Descriptor sampling, softmax, NMS, matching: fp32 always */
+                                      deviation report only);
+                                   3: as 1 with fp16 halves (operands pre-scaled by exact powers of two so that both halves
+                                      stay in fp16's range): about 22 significant bits per operand, results within twice
+                                      the rounding noise of an fp32 evaluation.
+                                   Descriptor sampling, softmax, NMS, matching: fp32 always */
 } ppg_config;
 
 void ppg_default_config(ppg_config* cfg, int width, int height);

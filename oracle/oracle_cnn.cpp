@@ -174,6 +174,45 @@ inline float bf16_round(float x) {
     return r;
 }
 
+// float rounded to the nearest fp16 value (ties to even, subnormals kept), returned as float; |x| < 65520
+inline float f16_round(float x) {
+    if (std::fabs(x) < 0x1p-14f) return std::nearbyint(x * 0x1p24f) * 0x1p-24f;  // fp16 subnormal grid (nearbyint: to even)
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = (u + 0xFFFu + ((u >> 13) & 1u)) & 0xFFFFE000u;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
+}
+
+// The fp16 hi/lo split mode (precision 3): operands are first scaled by exact powers of two (activations 2^5, weights
+// 2^10) so that hi and lo stay in fp16's normal range, split as hi = f16(v), lo = f16(v - hi), the three products
+// accumulated in fp32, and the sum scaled back by 2^-15 before the bias.  About 22 significant bits per operand.
+void conv3x3_f16split(const std::vector<float>& in, int H, int W, const Conv& c, std::vector<float>& out) {
+    const int Cin = c.cin, Cout = c.cout, C2 = 3 * Cin;
+    const float sa = 0x1p5f, sw = 0x1p10f;
+    std::vector<float> in2((size_t)H * W * C2);
+    for (size_t p = 0; p < (size_t)H * W; p++)
+        for (int ci = 0; ci < Cin; ci++) {
+            const float v = in[p * Cin + ci] * sa, hi = f16_round(v), lo = f16_round(v - hi);
+            in2[p * C2 + ci] = hi; in2[p * C2 + Cin + ci] = lo; in2[p * C2 + 2 * Cin + ci] = hi;
+        }
+    Conv c2;
+    c2.cin = C2; c2.cout = Cout; c2.ks = 3; c2.b.assign(Cout, 0.0f);
+    c2.w.resize((size_t)9 * C2 * Cout);
+    for (int t = 0; t < 9; t++)
+        for (int ci = 0; ci < Cin; ci++)
+            for (int o = 0; o < Cout; o++) {
+                const float v = c.w[((size_t)t * Cin + ci) * Cout + o] * sw, hi = f16_round(v), lo = f16_round(v - hi);
+                c2.w[((size_t)t * C2 + ci) * Cout + o] = hi;
+                c2.w[((size_t)t * C2 + Cin + ci) * Cout + o] = hi;
+                c2.w[((size_t)t * C2 + 2 * Cin + ci) * Cout + o] = lo;
+            }
+    conv3x3(in2, H, W, c2, out);
+    for (size_t p = 0; p < (size_t)H * W; p++)
+        for (int o = 0; o < Cout; o++) out[p * Cout + o] = out[p * Cout + o] * 0x1p-15f + c.b[o];
+}
+
 void conv3x3_lowp(const std::vector<float>& in, int H, int W, const Conv& c, int terms, std::vector<float>& out) {
     const int Cin = c.cin, Cout = c.cout, C2 = terms * Cin;
     std::vector<float> in2((size_t)H * W * C2);
@@ -293,9 +332,10 @@ int ppgo_inference(const ppgo_net* n, const uint8_t* img, int H, int W,
 // multiple of 16 channels and whose output has at least 64: all but conv1a and the 16 -> 16 EdgeHeatmap block).
 int ppgo_inference_prec(const ppgo_net* n, const uint8_t* img, int H, int W, int precision,
                         float* feat, float* junc, float* heat, float* desc) {
-    if (!n || H % 8 || W % 8 || precision < 0 || precision > 2) return -1;
+    if (!n || H % 8 || W % 8 || precision < 0 || precision > 3) return -1;
     auto conv3x3 = [&](const std::vector<float>& in, int h_, int w_, const Conv& cv, std::vector<float>& out) {
-        if (precision != 0 && cv.cin % 16 == 0 && cv.cout >= 64) conv3x3_lowp(in, h_, w_, cv, precision == 1 ? 3 : 1, out);
+        if (precision == 3 && cv.cin % 16 == 0 && cv.cout >= 64) conv3x3_f16split(in, h_, w_, cv, out);
+        else if (precision != 0 && cv.cin % 16 == 0 && cv.cout >= 64) conv3x3_lowp(in, h_, w_, cv, precision == 1 ? 3 : 1, out);
         else ::conv3x3(in, h_, w_, cv, out);
     };
     std::vector<float> a((size_t)H * W), b, c;

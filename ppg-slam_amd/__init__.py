@@ -86,7 +86,8 @@ def _p(a):
 
 
 def default_config(width, height, max_batch=1, max_num=500, weights=DEFAULT_WEIGHTS, device_id=0, precision=0):
-    """precision: 0 fp32 (parity path), 1 bf16 hi/lo split with three products, 2 plain bf16 (3x3 convolutions)."""
+    """precision: 0 fp32 (parity path), 1 bf16 hi/lo split with three products, 2 plain bf16, 3 fp16 hi/lo split
+    (3x3 convolutions)."""
     cfg = Config()
     lib().ppg_default_config(C.byref(cfg), width, height)
     cfg.precision = precision

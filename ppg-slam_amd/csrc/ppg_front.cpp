@@ -346,6 +346,23 @@ inline float bf16_float(uint16_t h) {
     return x;
 }
 
+// float -> fp16 bits, round to nearest even, subnormals kept (|x| < 65520), and back
+inline uint16_t f16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const float ax = std::fabs(x);
+    if (ax < 0x1p-14f) return sign | (uint16_t)std::nearbyint(ax * 0x1p24f);  // subnormal grid (0x0400 = 2^-14 when it rounds up)
+    u &= 0x7FFFFFFFu;
+    u = (u + 0xFFFu + ((u >> 13) & 1u)) >> 13;       // 10-bit mantissa, exponent still biased by 127
+    return sign | (uint16_t)(u - ((127 - 15) << 10));
+}
+inline float f16_float(uint16_t h) {
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    float v = e == 0 ? (float)m * 0x1p-24f : std::ldexp((float)(m | 1024u), (int)e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+
 // Pack OIHW weights into the LDS image order of conv_mfma_kernel:
 //   [cout block][cin chunk][group of 8 cin][tap][half h][cout in block][4 cin]
 // with cin = chunk*KC + g*8 + h*4 + s.  `ps2` permutes couts so that a pixel-shuffle block's packed
@@ -385,7 +402,8 @@ int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::str
                         }
     // Reduced-precision modes: the 3x3 layers with 64-cout blocks run on the bf16 MFMA.  Image order of
     // conv_bf16_kernel: [cout block][chunk of 16 cin][tap][half h][hi | lo][cout in block][8 cin], cin = chunk*16 +
-    // h*8 + j; hi = bf16(w) rounded to nearest even, lo = bf16(w - hi).  Same byte count as the fp32 image.
+    // h*8 + j; hi = bf16(w) rounded to nearest even, lo = bf16(w - hi) (precision 3: fp16 halves of 2^10 * w).  Same byte
+    // count as the fp32 image.
     dc.lowp = c->cfg.precision != 0 && ks == 3 && nt == 2 && cin % 16 == 0;
     if (dc.lowp) {
         std::vector<uint16_t> pb(pk.size() * 2, 0);
@@ -399,9 +417,16 @@ int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::str
                             if (o < 0) continue;
                             for (int j = 0; j < 8; j++) {
                                 const int ci = ch * 16 + h * 8 + j;
-                                const float wv = w.v[((size_t)o * cin + ci) * taps + tap];
-                                const uint16_t hi = bf16_rne(wv);
-                                const uint16_t lo = bf16_rne(wv - bf16_float(hi));
+                                float wv = w.v[((size_t)o * cin + ci) * taps + tap];
+                                uint16_t hi, lo;
+                                if (c->cfg.precision == 3) {  // fp16 halves of the weight scaled by 2^10
+                                    wv = std::min(std::max(wv * 0x1p10f, -65504.f), 65504.f);  // |w| < 64 in these networks
+                                    hi = f16_rne(wv);
+                                    lo = f16_rne(wv - f16_float(hi));
+                                } else {
+                                    hi = bf16_rne(wv);
+                                    lo = bf16_rne(wv - bf16_float(hi));
+                                }
                                 const size_t base = (((((size_t)nb * nch16 + ch) * taps + tap) * 2 + h) * 2) * NB;
                                 pb[((base + nn) * 8) + j] = hi;
                                 pb[((base + NB + nn) * 8) + j] = lo;
@@ -676,7 +701,7 @@ static int create_impl(ppg_ctx* c) {
     if (f.junction_max_num < 1 || f.junction_max_num > 4096) return fail(c, PPG_EINVAL, "junction_max_num must be 1..4096");
     if (f.max_batch < 1 || f.max_batch > 64) return fail(c, PPG_EINVAL, "max_batch must be 1..64");
     if (f.heatmap_refine_sz < 1 || f.heatmap_refine_sz > 16) return fail(c, PPG_EINVAL, "heatmap_refine_sz must be 1..16");
-    if (f.precision < 0 || f.precision > 2) return fail(c, PPG_EINVAL, "precision %d is not built", f.precision);
+    if (f.precision < 0 || f.precision > 3) return fail(c, PPG_EINVAL, "precision %d is not built", f.precision);
     if (!f.weights_path) return fail(c, PPG_EINVAL, "weights_path is NULL");
     c->weights_path = f.weights_path;
     c->cfg.weights_path = c->weights_path.c_str();

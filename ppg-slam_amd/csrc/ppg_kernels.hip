@@ -317,6 +317,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// The fp16 variant of the split (F16): operands are first scaled by exact powers of two (activations 2^5, weights
+// 2^10 on the host) so that hi and lo stay inside fp16's narrow exponent range, and the accumulators are scaled back
+// by 2^-15 before the bias.  fp16 keeps 11 bits per half instead of 8: the three products carry about 22 significant
+// bits of each operand, which brings the result to within twice the rounding noise of an fp32 evaluation.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float kF16ActScale = 0x1p5f, kF16AccUnscale = 0x1p-15f;  // weights carry 2^10
+
+__device__ __forceinline__ void split_f16(float x0, float x1, unsigned& hi, unsigned& lo) {
+    // saturate instead of overflowing to infinity (activations beyond 2047 do not occur in these networks)
+    x0 = fminf(fmaxf(x0 * kF16ActScale, -65504.f), 65504.f);
+    x1 = fminf(fmaxf(x1 * kF16ActScale, -65504.f), 65504.f);
+    const f16x2 h = {(_Float16)x0, (_Float16)x1};  // round to nearest even
+    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
 // two floats -> their bf16 hi parts and the bf16 of the remainders, each pair packed into one dword
 __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
     const f32x2 x = {x0, x1};
@@ -325,7 +343,7 @@ __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, uns
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
-template <int NT, bool FUSE1A, int MW, int TERMS>
+template <int NT, bool FUSE1A, int MW, int TERMS, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     constexpr int KC = 16;
     constexpr int TW = MW, TH = 256 / MW;
@@ -436,8 +454,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 unsigned h0, l0, h1, l1;
-                split_bf16(vin[k][q][0], vin[k][q][1], h0, l0);
-                split_bf16(vin[k][q][2], vin[k][q][3], h1, l1);
+                if (F16) {
+                    split_f16(vin[k][q][0], vin[k][q][1], h0, l0);
+                    split_f16(vin[k][q][2], vin[k][q][3], h1, l1);
+                } else {
+                    split_bf16(vin[k][q][0], vin[k][q][1], h0, l0);
+                    split_bf16(vin[k][q][2], vin[k][q][3], h1, l1);
+                }
                 hi[2 * q] = h0; hi[2 * q + 1] = h1;
                 lo[2 * q] = l0; lo[2 * q + 1] = l1;
             }
@@ -461,6 +484,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     __syncthreads();
     const unsigned char* ins = smem;
     const unsigned char* ws = smem + IN_BYTES_P;
+    auto mma = [](bf16x8 wv, bf16x8 xv, f32x16 c) {
+        if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv), __builtin_bit_cast(f16x8, xv), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, c, 0, 0, 0);
+    };
     for (int c = 0; c < nchunks; c++) {
         if (c + 1 < nchunks) fetch(c + 1);
 #pragma unroll
@@ -484,15 +511,23 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
                     if (TERMS == 3) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[n], xh[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[n], xl[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = mma(wl[n], xh[m], acc[m][n]);
+                        acc[m][n] = mma(wh[n], xl[m], acc[m][n]);
                     }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[n], xh[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = mma(wh[n], xh[m], acc[m][n]);
                 }
         }
         __syncthreads();
         if (c + 1 < nchunks) stash();
         __syncthreads();
+    }
+    if (F16) {
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[m][n][r] *= kF16AccUnscale;
     }
     conv_store<NT, MW>(a, acc, wave, li, lh, x0, y0, b, nb);
 }
@@ -507,15 +542,19 @@ hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     if (a.img && (ks != 3 || nt != 2 || a.Cin != 64 || a.mw != 32)) return hipErrorInvalidValue;
     if (a.prec != 0) {
         // reduced-precision modes exist for the 3x3 layers with 64-cout blocks (98 % of the arithmetic)
-        if (ks != 3 || nt != 2 || a.Cin % 16 || (a.prec != 1 && a.prec != 2)) return hipErrorInvalidValue;
+        if (ks != 3 || nt != 2 || a.Cin % 16 || a.prec < 1 || a.prec > 3) return hipErrorInvalidValue;
         if (a.prec == 1) {
             if (a.img) hipLaunchKernelGGL((conv_bf16_kernel<2, true, 32, 3>), grid, block, 0, s, a);
             else if (a.mw == 16) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 16, 3>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 3>), grid, block, 0, s, a);
-        } else {
+        } else if (a.prec == 2) {
             if (a.img) hipLaunchKernelGGL((conv_bf16_kernel<2, true, 32, 1>), grid, block, 0, s, a);
             else if (a.mw == 16) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 16, 1>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 1>), grid, block, 0, s, a);
+        } else {
+            if (a.img) hipLaunchKernelGGL((conv_bf16_kernel<2, true, 32, 3, true>), grid, block, 0, s, a);
+            else if (a.mw == 16) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 16, 3, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 3, true>), grid, block, 0, s, a);
         }
         return hipGetLastError();
     }

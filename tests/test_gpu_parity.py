@@ -596,7 +596,7 @@ def test_match_mutual_vs_oracle(pkg, orc):
 
 # ---- reduced-precision convolution modes (precision 1: bf16 hi/lo split, 2: plain bf16) ----
 
-@pytest.mark.parametrize("precision", [1, 2])
+@pytest.mark.parametrize("precision", [1, 2, 3])
 def test_reduced_precision_cnn_vs_oracle(precision, pkg, onet, synth):
     """The bf16 MFMA kernels against the oracle's statement of the same arithmetic (operands rounded to bf16 hi
     (+ lo), exact products, fp32 accumulation).  Sizes cover the 8 x 32 and 16 x 16 tiles, ragged edges and the
@@ -605,7 +605,7 @@ def test_reduced_precision_cnn_vs_oracle(precision, pkg, onet, synth):
     bit: 2^-17 (8e-6) of the value with the hi/lo split, 2^-8 (4e-3) with plain bf16.  Measured: 0.4-1.6e-5
     (heat 2-3e-5) and 1.5-3.6e-3 (heat 7e-3) of the tensor's scale; a misplaced operand half shows as >= 1e-3
     in the split mode."""
-    tol = {1: (4e-5, 1e-4), 2: (1.5e-2, 3e-2)}[precision]
+    tol = {1: (4e-5, 1e-4), 2: (1.5e-2, 3e-2), 3: (1e-5, 3e-5)}[precision]
     for (H, W, seed, kind) in ((72, 104, 41, "sparse"), (128, 160, 42, "dense"), (240, 320, 43, "sparse")):
         img = synth.make_frame(H, W, seed, 0, kind)
         ctx = get_ctx(pkg, W, H, precision=precision)
@@ -660,7 +660,7 @@ def test_plain_bf16_deviation_report(pkg, synth, capsys):
     assert float(dd.max()) < 0.5
 
 
-@pytest.mark.parametrize("precision", [1, 2])
+@pytest.mark.parametrize("precision", [1, 2, 3])
 def test_reduced_precision_batch_equals_single(precision, pkg, synth):
     """The reduced-precision kernels are deterministic and independent of the position in the batch: every frame of
     a batch is bit-identical to the same frame extracted alone (same kernels, same order of operations)."""
@@ -672,3 +672,21 @@ def test_reduced_precision_batch_equals_single(precision, pkg, synth):
     for r, s in zip(ctx.extract_batch(imgs), singles):
         for k in ("xy", "score", "un", "out", "desc", "edge_idx", "conn_idx", "coline_pairs"):
             assert np.array_equal(r[k], s[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("name,kind", FULL)
+def test_f16_split_full_frame_vs_fp32_golden(name, kind, pkg, synth):
+    """precision 3 against the fp32 goldens of the reference nets, with the tolerances of the fp32 path's own
+    end-to-end test doubled: score map 2e-5, key points equivalent up to ties within 4e-5, descriptors 1e-4
+    (bar 1e-3), edge sets within two edges."""
+    g = golden(name)
+    H, W, seed, maxnum = [int(v) for v in g["meta"]]
+    ctx = get_ctx(pkg, W, H, maxnum, precision=3)
+    for t in (0, 1):
+        r = ctx.extract(synth.make_frame(H, W, seed, t, kind))
+        assert float(np.abs(ctx.read_tensor(pkg.T_SCORE)[::4, ::4] - g[f"score_sub_{t}"]).max()) < 2e-5
+        swaps = assert_keypoints_equivalent(r["xy"], r["score"], g[f"kp_xy_{t}"], g[f"kp_score_{t}"], tol=4e-5)
+        ea, eb = edge_coord_set(r["edge_idx"], r["xy"]), edge_coord_set(g[f"edge_idx_{t}"], g[f"kp_xy_{t}"])
+        assert len(ea ^ eb) <= 2, len(ea ^ eb)
+        if swaps == 0:
+            assert float(np.linalg.norm(r["desc"] - g[f"kp_desc_{t}"], axis=1).max()) < 1e-4

@@ -7,7 +7,7 @@ import importlib
 synth=importlib.import_module(pkg.__name__+'.synth')
 net=O.Net()
 nhwc=lambda a: np.ascontiguousarray(np.transpose(a,(1,2,0)))
-for prec in (0,1,2):
+for prec in (0,1,2,3):
     for (H,W,seed,kind) in ((72,104,41,"sparse"),(128,160,42,"dense"),(240,320,43,"sparse")):
         img=synth.make_frame(H,W,seed,0,kind)
         ctx=pkg.Context(pkg.default_config(W,H,precision=prec))
