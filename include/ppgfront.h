@@ -58,7 +58,9 @@ typedef struct ppg_config {
                                       deviation report only);
                                    3: as 1 with fp16 halves (operands pre-scaled by exact powers of two so that both halves
                                       stay in fp16's range): about 22 significant bits per operand, results within twice
-                                      the rounding noise of an fp32 evaluation.
+                                      the rounding noise of an fp32 evaluation.  Range: activations entering a 3x3 layer
+                                      saturate at +-2047 and |weight| at 63.9 (the shipped networks reach 212 and 1.55
+                                      on full-contrast images).
                                    Descriptor sampling, softmax, NMS, matching: fp32 always */
 } ppg_config;
 

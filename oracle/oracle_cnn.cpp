@@ -197,6 +197,13 @@ void conv3x3_f16split(const std::vector<float>& in, int H, int W, const Conv& c,
             const float v = in[p * Cin + ci] * sa, hi = f16_round(v), lo = f16_round(v - hi);
             in2[p * C2 + ci] = hi; in2[p * C2 + Cin + ci] = lo; in2[p * C2 + 2 * Cin + ci] = hi;
         }
+    if (getenv("PPGO_PRINT_RANGE")) {  // how much of fp16's range (65504) the scaled operands use
+        float ma = 0.f, mw = 0.f;
+        for (float v : in) ma = std::max(ma, std::fabs(v));
+        for (float v : c.w) mw = std::max(mw, std::fabs(v));
+        fprintf(stderr, "f16 split conv %dx%d %d->%d: max |activation| %.3f (scaled %.0f), max |weight| %.4f (scaled %.1f)\n",
+                H, W, Cin, Cout, ma, ma * sa, mw, mw * sw);
+    }
     Conv c2;
     c2.cin = C2; c2.cout = Cout; c2.ks = 3; c2.b.assign(Cout, 0.0f);
     c2.w.resize((size_t)9 * C2 * Cout);
