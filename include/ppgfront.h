@@ -26,6 +26,7 @@ extern "C" {
 #define PPG_EIO (-3)      /* weight blob unreadable or malformed */
 #define PPG_ENOMEM (-4)
 #define PPG_ECAP (-5)     /* a capacity given at create time was exceeded */
+#define PPG_ERANGE (-6)   /* precision 3: an activation left the range of the fp16 split (use precision 0 or 1) */
 
 typedef struct ppg_ctx ppg_ctx;
 

@@ -64,6 +64,7 @@ struct Slot {
     uint32_t* cand_ij = nullptr;
     int32_t* d_match = nullptr;   // [B][maxn]
     int* d_mcounts = nullptr;     // [B]
+    int* sat = nullptr;           // precision 3: set by the convolutions when an activation saturated the fp16 split
     float *junc = nullptr, *hs2 = nullptr, *descmap = nullptr;  // CNN outputs read by the post stream
     hipEvent_t cnn_done = nullptr;
     // pinned host mirrors
@@ -74,6 +75,7 @@ struct Slot {
     uint32_t* h_cand_ij = nullptr;
     int32_t* h_match = nullptr;
     int* h_mcounts = nullptr;
+    int* h_sat = nullptr;
     uint8_t* h_img = nullptr;     // staging for host images
     std::vector<FrameHost> frames;
     std::vector<int> nkp;         // key points per frame, known after the slot was collected
@@ -564,7 +566,7 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
              const uint8_t* fused_img = nullptr) {
     ppg::ConvArgs a;
     if (fused_img) { a.img = fused_img; a.w1a = c->c1a_w; a.b1a = c->c1a_b; }
-    a.in = in; a.wpk = dc.w; a.prec = dc.lowp ? c->cfg.precision : 0;
+    a.in = in; a.wpk = dc.w; a.prec = dc.lowp ? c->cfg.precision : 0; a.sat = c->slot[c->cur].sat;
     a.B = n; a.H = H; a.W = W; a.Cin = dc.cin;
     a.mw = fused_img ? 32 : pick_tile(dc, H, W, mode);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw); a.nblk = dc.nblk;
@@ -581,7 +583,7 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
 // 12 cout blocks instead of three with 4, so the small 1/8-resolution grid fills the chip better.
 int run_heads(ppg_ctx* c, int n, int H, int W) {
     ppg::ConvArgs a;
-    a.in = c->feat; a.wpk = c->heads_w; a.prec = c->pa.lowp ? c->cfg.precision : 0;
+    a.in = c->feat; a.wpk = c->heads_w; a.prec = c->pa.lowp ? c->cfg.precision : 0; a.sat = c->slot[c->cur].sat;
     a.B = n; a.H = H; a.W = W; a.Cin = c->pa.cin;
     a.mw = pick_tile(c->pa, H, W, ppg::CONV_PLAIN);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
@@ -784,6 +786,7 @@ static int create_impl(ppg_ctx* c) {
 #define DS(ptr, n) do { rc = dalloc(c, &sl.ptr, (n)); if (rc) return rc; } while (0)
 #define HS(ptr, n) do { rc = halloc(c, &sl.ptr, (n)); if (rc) return rc; } while (0)
         DS(counters, B * 8);
+        DS(sat, 1);
         DS(kp_xy, B * c->maxn * 2);
         DS(kp_score, B * c->maxn);
         DS(kp_un, B * c->maxn * 2);
@@ -797,6 +800,8 @@ static int create_impl(ppg_ctx* c) {
         DS(hs2, B * HW * 4);
         DS(descmap, B * hw * 256);
         HS(h_counters, B * 8);
+        HS(h_sat, 1);
+        sl.h_sat[0] = 0;
         HS(h_kp_xy, B * c->maxn * 2);
         HS(h_kp_score, B * c->maxn);
         HS(h_kp_un, B * c->maxn * 2);
@@ -893,6 +898,7 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
         HIPCHK(c, hipMemcpyAsync(c->d_img, c->h_img, n * HW, hipMemcpyHostToDevice, c->stream));
         dimg = c->d_img;
     }
+    if (c->cfg.precision == 3) HIPCHK(c, hipMemsetAsync(c->slot[c->cur].sat, 0, sizeof(int), c->stream));
     const int H = c->H, W = c->W;
     // conv1a (u8 -> /255 -> conv 1->64 -> ReLU, backbone.py:28) is evaluated inside conv1b's staging, so the
     // full-resolution 64-channel tensor never goes to memory; PPG_UNFUSED_CONV1A=1 keeps the separate kernel.
@@ -984,6 +990,7 @@ static int enqueue_d2h(ppg_ctx* c, int si, int n) {
     const int M = c->maxn;
     hipStream_t s = c->post;
     HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.counters, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, s));
+    if (c->cfg.precision == 3) HIPCHK(c, hipMemcpyAsync(sl.h_sat, sl.sat, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_xy, sl.kp_xy, sizeof(int32_t) * 2 * M * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_score, sl.kp_score, sizeof(float) * M * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_un, sl.kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
@@ -1012,6 +1019,8 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
     const double t_sync0 = now_ms();
     HIPCHK(c, hipEventSynchronize(sl.done));
     if (c->prof) { c->prof_ms[PPG_PROF_HOST_WAIT] += now_ms() - t_sync0; c->prof_launches[PPG_PROF_HOST_WAIT] += 1; }
+    if (c->cfg.precision == 3 && sl.h_sat[0])
+        return fail(c, PPG_ERANGE, "an activation left the range of the fp16 split (|x| > 2047): use precision 0 or 1");
     bool more = false;
     for (int b = 0; b < n; b++) {
         const int* cnt = sl.h_counters + b * 8;

@@ -28,6 +28,7 @@ struct ConvArgs {
     const float* b1a = nullptr;    // [64]
     const float* wpk;    // packed per (cout block, cin chunk), the blocks of all groups concatenated
                          // (prec != 0: the bf16 hi/lo image of conv_bf16_kernel, same size)
+    int* sat = nullptr;  // prec 3: set to 1 when an activation saturates the fp16 split
     int prec = 0;        // 0: fp32 MFMA; 1: bf16 hi/lo split, three products; 2: plain bf16; 3: fp16 hi/lo split (3x3, nt = 2 only)
     int B, H, W, Cin;
     int tiles_x, tiles_y, nblk;  // nblk = cout blocks of all groups together

@@ -325,10 +325,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float kF16ActScale = 0x1p5f, kF16AccUnscale = 0x1p-15f;  // weights carry 2^10
 
-__device__ __forceinline__ void split_f16(float x0, float x1, unsigned& hi, unsigned& lo) {
-    // saturate instead of overflowing to infinity (activations beyond 2047 do not occur in these networks)
-    x0 = fminf(fmaxf(x0 * kF16ActScale, -65504.f), 65504.f);
-    x1 = fminf(fmaxf(x1 * kF16ActScale, -65504.f), 65504.f);
+__device__ __forceinline__ void split_f16(float x0, float x1, unsigned& hi, unsigned& lo, bool& sat) {
+    // saturate instead of overflowing to infinity, and report it (activations beyond 2047 do not occur in these
+    // networks; NaN compares false and propagates)
+    x0 *= kF16ActScale; x1 *= kF16ActScale;
+    sat |= fabsf(x0) > 65504.f || fabsf(x1) > 65504.f;
+    x0 = fminf(fmaxf(x0, -65504.f), 65504.f);
+    x1 = fminf(fmaxf(x1, -65504.f), 65504.f);
     const f16x2 h = {(_Float16)x0, (_Float16)x1};  // round to nearest even
     const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
     hi = __builtin_bit_cast(unsigned, h);
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
 
     f32x4 vin[IN_PER_T][2];
     u32x4 vw[W_PER_T];
+    bool saturated = false;
     auto fetch = [&](int c) {
 #pragma unroll
         for (int k = 0; k < W_PER_T; k++)
@@ -455,8 +459,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
             for (int q = 0; q < 2; q++) {
                 unsigned h0, l0, h1, l1;
                 if (F16) {
-                    split_f16(vin[k][q][0], vin[k][q][1], h0, l0);
-                    split_f16(vin[k][q][2], vin[k][q][3], h1, l1);
+                    split_f16(vin[k][q][0], vin[k][q][1], h0, l0, saturated);
+                    split_f16(vin[k][q][2], vin[k][q][3], h1, l1, saturated);
                 } else {
                     split_bf16(vin[k][q][0], vin[k][q][1], h0, l0);
                     split_bf16(vin[k][q][2], vin[k][q][3], h1, l1);
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
         __syncthreads();
     }
     if (F16) {
+        if (saturated && a.sat) atomicOr(a.sat, 1);
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll

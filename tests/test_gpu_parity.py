@@ -690,3 +690,32 @@ def test_f16_split_full_frame_vs_fp32_golden(name, kind, pkg, synth):
         assert len(ea ^ eb) <= 2, len(ea ^ eb)
         if swaps == 0:
             assert float(np.linalg.norm(r["desc"] - g[f"kp_desc_{t}"], axis=1).max()) < 1e-4
+
+
+def test_f16_split_reports_saturation(pkg, synth, tmp_path):
+    """precision 3 saturates activations at +-2047 and must say so: with conv1a's weights scaled 40x the first layer's
+    outputs leave that range and the library fails with PPG_ERANGE; the untouched weights pass."""
+    import struct
+    blob = bytearray(open(pkg.DEFAULT_WEIGHTS, "rb").read())
+    assert blob[:8] == b"PPGW0001"
+    n = struct.unpack_from("<I", blob, 8)[0]
+    hit = False
+    for k in range(n):
+        base = 16 + 96 * k
+        name = bytes(blob[base:base + 56]).split(b"\0")[0].decode()
+        off, nbytes = struct.unpack_from("<QQ", blob, base + 80)  # name[56], ndim, dims[4], 4 bytes of padding
+        if name in ("backbone.conv1a.weight", "backbone.conv1a.bias"):
+            w = np.frombuffer(bytes(blob[off:off + nbytes]), np.float32) * np.float32(40.0)
+            blob[off:off + nbytes] = w.tobytes()
+            hit = True
+    assert hit
+    path = str(tmp_path / "scaled.bin")
+    open(path, "wb").write(bytes(blob))
+    img = synth.make_frame(96, 128, 3, 0, "dense")
+    good = pkg.Context(pkg.default_config(128, 96, precision=3))
+    assert good.extract(img)["n"] > 0
+    good.close()
+    # the warm-up frame of ppg_create already runs the networks, so the error may surface there
+    with pytest.raises(pkg.PPGError, match="range of the fp16 split"):
+        ctx = pkg.Context(pkg.default_config(128, 96, weights=path, precision=3))
+        ctx.extract(img)
