@@ -354,3 +354,17 @@ def test_aten_op_sequence_matches_goldens_and_oracle(onet, synth):
         assert float(np.abs(got - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max())), name
     o = onet.inference(img)
     assert float(np.abs(o["feat"] - feat[0].numpy()).max()) <= 1e-5 * float(np.abs(o["feat"]).max())
+
+
+def test_reduced_precision_statements_against_the_reference_nets(onet):
+    """The oracle's statements of the build's reduced-precision convolution modes, measured against the goldens of the
+    reference nets: the fp16 hi/lo split stays at the fp32 noise floor, the bf16 split within a few 1e-5, plain bf16 at
+    the percent level (what each mode of the library is then compared with on the GPU)."""
+    g = golden("cnn_96x128_s1_sparse.npz")
+    bound = {0: 4e-6, 3: 8e-6, 1: 1e-4, 2: 5e-2}
+    floor = {2: 1e-3}
+    for prec, tol in bound.items():
+        t = onet.inference(g["img"], prec)
+        worst = max(float(np.abs(t[k] - g[k]).max() / np.abs(g[k]).max()) for k in ("feat", "junc", "desc"))
+        assert worst <= tol, (prec, worst)
+        assert worst >= floor.get(prec, 0.0), (prec, worst)
