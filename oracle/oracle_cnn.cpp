@@ -335,14 +335,14 @@ int ppgo_inference(const ppgo_net* n, const uint8_t* img, int H, int W,
 }
 
 // precision 0: fp32 (the reference graphs as torch evaluates them on the CPU); 1 / 2: the build's bf16 split /
-// plain bf16 modes, applied to the layers the build applies them to (every 3x3 convolution whose input has a
-// multiple of 16 channels and whose output has at least 64: all but conv1a and the 16 -> 16 EdgeHeatmap block).
+// plain bf16 / fp16 split modes, applied to the layers the build applies them to (every 3x3 convolution whose input
+// has a multiple of 16 channels: all but conv1a).
 int ppgo_inference_prec(const ppgo_net* n, const uint8_t* img, int H, int W, int precision,
                         float* feat, float* junc, float* heat, float* desc) {
     if (!n || H % 8 || W % 8 || precision < 0 || precision > 3) return -1;
     auto conv3x3 = [&](const std::vector<float>& in, int h_, int w_, const Conv& cv, std::vector<float>& out) {
-        if (precision == 3 && cv.cin % 16 == 0 && cv.cout >= 64) conv3x3_f16split(in, h_, w_, cv, out);
-        else if (precision != 0 && cv.cin % 16 == 0 && cv.cout >= 64) conv3x3_lowp(in, h_, w_, cv, precision == 1 ? 3 : 1, out);
+        if (precision == 3 && cv.cin % 16 == 0) conv3x3_f16split(in, h_, w_, cv, out);
+        else if (precision != 0 && cv.cin % 16 == 0) conv3x3_lowp(in, h_, w_, cv, precision == 1 ? 3 : 1, out);
         else ::conv3x3(in, h_, w_, cv, out);
     };
     std::vector<float> a((size_t)H * W), b, c;

@@ -546,8 +546,16 @@ hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     if ((long)a.H * a.W * a.Cin * 4 > 0x7fffffffL) return hipErrorInvalidValue;
     if (a.img && (ks != 3 || nt != 2 || a.Cin != 64 || a.mw != 32)) return hipErrorInvalidValue;
     if (a.prec != 0) {
-        // reduced-precision modes exist for the 3x3 layers with 64-cout blocks (98 % of the arithmetic)
-        if (ks != 3 || nt != 2 || a.Cin % 16 || a.prec < 1 || a.prec > 3) return hipErrorInvalidValue;
+        // reduced-precision modes exist for the 3x3 layers whose input has a multiple of 16 channels (all but conv1a)
+        if (ks != 3 || (nt != 1 && nt != 2) || a.Cin % 16 || a.prec < 1 || a.prec > 3) return hipErrorInvalidValue;
+        if (nt == 1) {
+            // 32-cout blocks (the 16 -> 16 EdgeHeatmap block): 8 x 32 tile only
+            if (a.img || a.mw != 32) return hipErrorInvalidValue;
+            if (a.prec == 1) hipLaunchKernelGGL((conv_bf16_kernel<1, false, 32, 3>), grid, block, 0, s, a);
+            else if (a.prec == 2) hipLaunchKernelGGL((conv_bf16_kernel<1, false, 32, 1>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv_bf16_kernel<1, false, 32, 3, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
         if (a.prec == 1) {
             if (a.img) hipLaunchKernelGGL((conv_bf16_kernel<2, true, 32, 3>), grid, block, 0, s, a);
             else if (a.mw == 16) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 16, 3>), grid, block, 0, s, a);
