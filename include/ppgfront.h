@@ -52,7 +52,8 @@ typedef struct ppg_config {
     float line_heatmap_thresh;  /* LINE_HEATMAP_THRESH */
     float line_inlier_rate;     /* LINE_INLIER_RATE */
     int precision;              /* 0: fp32 operands, fp32 MFMA accumulate (parity path: integer outputs exact);
-                                   1: the 3x3 convolutions with 64-cout blocks on the bf16 MFMA with every operand split
+                                   1: the convolutions (all but the one-channel first layer and the final 4->2 one) on the
+                                      bf16 MFMA with every operand split
                                       into bf16 hi + lo and three products (hi*hi + hi*lo + lo*hi), fp32 accumulate:
                                       descriptors within 1e-3 of the fp32 path, key-point sets equal up to near-ties;
                                    2: the same layers with plain bf16 operands (outside the parity bar; for the

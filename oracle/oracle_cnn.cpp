@@ -261,6 +261,34 @@ void conv1x1(const std::vector<float>& in, int H, int W, const Conv& c, std::vec
     }
 }
 
+// 1x1 layers in the reduced-precision modes: the same operand treatment as conv3x3_lowp / conv3x3_f16split
+void conv1x1_lowp(const std::vector<float>& in, int H, int W, const Conv& c, int precision, std::vector<float>& out) {
+    const int Cin = c.cin, Cout = c.cout;
+    const bool f16 = precision == 3;
+    const int terms = precision == 2 ? 1 : 3, C2 = terms * Cin;
+    const float sa = f16 ? 0x1p5f : 1.f, sw = f16 ? 0x1p10f : 1.f, us = f16 ? 0x1p-15f : 1.f;
+    auto rnd = [&](float v) { return f16 ? f16_round(v) : bf16_round(v); };
+    std::vector<float> in2((size_t)H * W * C2);
+    for (size_t p = 0; p < (size_t)H * W; p++)
+        for (int ci = 0; ci < Cin; ci++) {
+            const float v = in[p * Cin + ci] * sa, hi = rnd(v), lo = rnd(v - hi);
+            in2[p * C2 + ci] = hi;
+            if (terms == 3) { in2[p * C2 + Cin + ci] = lo; in2[p * C2 + 2 * Cin + ci] = hi; }
+        }
+    Conv c2;
+    c2.cin = C2; c2.cout = Cout; c2.ks = 1; c2.b.assign(Cout, 0.0f);
+    c2.w.resize((size_t)C2 * Cout);
+    for (int ci = 0; ci < Cin; ci++)
+        for (int o = 0; o < Cout; o++) {
+            const float v = c.w[(size_t)ci * Cout + o] * sw, hi = rnd(v), lo = rnd(v - hi);
+            c2.w[(size_t)ci * Cout + o] = hi;
+            if (terms == 3) { c2.w[(size_t)(Cin + ci) * Cout + o] = hi; c2.w[(size_t)(2 * Cin + ci) * Cout + o] = lo; }
+        }
+    conv1x1(in2, H, W, c2, out);
+    for (size_t p = 0; p < (size_t)H * W; p++)
+        for (int o = 0; o < Cout; o++) out[p * Cout + o] = out[p * Cout + o] * us + c.b[o];
+}
+
 void relu(std::vector<float>& a) {
     for (auto& v : a) v = v > 0.0f ? v : 0.0f;
 }
@@ -336,7 +364,7 @@ int ppgo_inference(const ppgo_net* n, const uint8_t* img, int H, int W,
 
 // precision 0: fp32 (the reference graphs as torch evaluates them on the CPU); 1 / 2: the build's bf16 split /
 // plain bf16 / fp16 split modes, applied to the layers the build applies them to (every 3x3 convolution whose input
-// has a multiple of 16 channels: all but conv1a).
+// has a multiple of 16 channels: all but conv1a; every 1x1 convolution whose input has a multiple of 32: convPb, convDb).
 int ppgo_inference_prec(const ppgo_net* n, const uint8_t* img, int H, int W, int precision,
                         float* feat, float* junc, float* heat, float* desc) {
     if (!n || H % 8 || W % 8 || precision < 0 || precision > 3) return -1;
@@ -344,6 +372,10 @@ int ppgo_inference_prec(const ppgo_net* n, const uint8_t* img, int H, int W, int
         if (precision == 3 && cv.cin % 16 == 0) conv3x3_f16split(in, h_, w_, cv, out);
         else if (precision != 0 && cv.cin % 16 == 0) conv3x3_lowp(in, h_, w_, cv, precision == 1 ? 3 : 1, out);
         else ::conv3x3(in, h_, w_, cv, out);
+    };
+    auto conv1x1 = [&](const std::vector<float>& in, int h_, int w_, const Conv& cv, std::vector<float>& out) {
+        if (precision != 0 && cv.cin % 32 == 0) conv1x1_lowp(in, h_, w_, cv, precision, out);
+        else ::conv1x1(in, h_, w_, cv, out);
     };
     std::vector<float> a((size_t)H * W), b, c;
     // PPGExtractor.cpp:151 — uint8 -> float, then a true division by 255

@@ -402,11 +402,12 @@ int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::str
                                 pk[dst] = w.v[((size_t)o * cin + ci) * taps + tap];
                             }
                         }
-    // Reduced-precision modes: the 3x3 layers whose input has a multiple of 16 channels run on the bf16 / fp16 MFMA.  Image order of
+    // Reduced-precision modes: the 3x3 layers whose input has a multiple of 16 channels and the 1x1 layers whose input
+    // has a multiple of 32 run on the bf16 / fp16 MFMA.  Image order of
     // conv_bf16_kernel: [cout block][chunk of 16 cin][tap][half h][hi | lo][cout in block][8 cin], cin = chunk*16 +
     // h*8 + j; hi = bf16(w) rounded to nearest even, lo = bf16(w - hi) (precision 3: fp16 halves of 2^10 * w).  Same byte
     // count as the fp32 image.
-    dc.lowp = c->cfg.precision != 0 && ks == 3 && cin % 16 == 0;
+    dc.lowp = c->cfg.precision != 0 && ((ks == 3 && cin % 16 == 0) || (ks == 1 && cin % 32 == 0));
     if (dc.lowp) {
         std::vector<uint16_t> pb(pk.size() * 2, 0);
         const int nch16 = cin / 16;

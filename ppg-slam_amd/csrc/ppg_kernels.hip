@@ -346,17 +346,21 @@ __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, uns
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
-template <int NT, bool FUSE1A, int MW, int TERMS, bool F16 = false>
+// KS = 1: a 1x1 layer has one tap per chunk, too little work between two barriers, so G chunks of 16 channels are staged
+// and consumed together (G = 2: 45 KiB of LDS).
+template <int NT, bool FUSE1A, int MW, int TERMS, bool F16 = false, int KS = 3, int G = 1>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
-    constexpr int KC = 16;
+    static_assert(!FUSE1A || (KS == 3 && G == 1), "the fused first layer is 3x3");
+    constexpr int KC = 16 * G, PAD = KS / 2, TAPS = KS * KS;
     constexpr int TW = MW, TH = 256 / MW;
-    constexpr int IH = TH + 2, IW = TW + 2, IN_PIX = IH * IW;
-    constexpr int PSTR = 80;  // bytes per staged pixel
+    constexpr int IH = TH + KS - 1, IW = TW + KS - 1, IN_PIX = IH * IW;
+    constexpr int PSTR = 64 * G + 16;  // bytes per staged pixel
     constexpr int NB = 32 * NT;
-    constexpr int IN_ITEMS = IN_PIX * 2;  // item = 8 channels of a pixel
+    constexpr int IPP = 2 * G;            // items per pixel; item = 8 channels of a pixel
+    constexpr int IN_ITEMS = IN_PIX * IPP;
     constexpr int IN_PER_T = (IN_ITEMS + 255) / 256;
-    constexpr int IN_BYTES_P = (IN_PER_T * 256 / 2) * PSTR;
-    constexpr int W_BYTES = 9 * 2 * 2 * NB * 16;
+    constexpr int IN_BYTES_P = (IN_PER_T * 256 / IPP) * PSTR;
+    constexpr int W_BYTES = G * TAPS * 2 * 2 * NB * 16;  // one stage; the packed image is [16-channel chunk][tap][half][hi|lo][cout]
     constexpr int W_PER_T = (W_BYTES / 16 + 255) / 256;
     constexpr int W_BYTES_P = W_PER_T * 256 * 16;
     constexpr int PH = IH + 2, PW = IW + 2;
@@ -384,10 +388,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     for (int k = 0; k < IN_PER_T; k++) {
         const int item = tid + 256 * k;
         // FUSE1A: the four lanes of an MFMA 4x4 block share a half and own four different pixels
-        const int pix = FUSE1A ? 128 * k + (tid >> 3) * 4 + (tid & 3) : item >> 1;
-        const int hh = FUSE1A ? (tid >> 2) & 1 : item & 1;
+        const int pix = FUSE1A ? 128 * k + (tid >> 3) * 4 + (tid & 3) : item / IPP;
+        const int hh = FUSE1A ? (tid >> 2) & 1 : item % IPP;  // which 8 channels of the stage
         const int py = pix / IW, px = pix % IW;
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const int gy = y0 + py - PAD, gx = x0 + px - PAD;
         lofs[k] = pix * PSTR + hh * 32;
         gofs[k] = NOWHERE;
         if (pix < IN_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
@@ -495,31 +499,34 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     for (int c = 0; c < nchunks; c++) {
         if (c + 1 < nchunks) fetch(c + 1);
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int ky = tap / 3, kx = tap % 3;
-            bf16x8 xh[2], xl[2], wh[NT], wl[NT];
+        for (int g = 0; g < G; g++) {
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const unsigned char* p = ins + ((prow(m, li) + ky) * IW + (pcol(li) + kx)) * PSTR + lh * 32;
-                xh[m] = *(const bf16x8*)p;
-                if (TERMS == 3) xl[m] = *(const bf16x8*)(p + 16);
-            }
+            for (int tap = 0; tap < TAPS; tap++) {
+                const int ky = tap / KS, kx = tap % KS;
+                bf16x8 xh[2], xl[2], wh[NT], wl[NT];
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                const unsigned char* p = ws + (((tap * 2 + lh) * 2) * NB + n * 32 + li) * 16;
-                wh[n] = *(const bf16x8*)p;
-                if (TERMS == 3) wl[n] = *(const bf16x8*)(p + NB * 16);
-            }
-#pragma unroll
-            for (int m = 0; m < 2; m++)
+                for (int m = 0; m < 2; m++) {
+                    const unsigned char* p = ins + ((prow(m, li) + ky) * IW + (pcol(li) + kx)) * PSTR + g * 64 + lh * 32;
+                    xh[m] = *(const bf16x8*)p;
+                    if (TERMS == 3) xl[m] = *(const bf16x8*)(p + 16);
+                }
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
-                    if (TERMS == 3) {
-                        acc[m][n] = mma(wl[n], xh[m], acc[m][n]);
-                        acc[m][n] = mma(wh[n], xl[m], acc[m][n]);
-                    }
-                    acc[m][n] = mma(wh[n], xh[m], acc[m][n]);
+                    const unsigned char* p = ws + ((((g * TAPS + tap) * 2 + lh) * 2) * NB + n * 32 + li) * 16;
+                    wh[n] = *(const bf16x8*)p;
+                    if (TERMS == 3) wl[n] = *(const bf16x8*)(p + NB * 16);
                 }
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        if (TERMS == 3) {
+                            acc[m][n] = mma(wl[n], xh[m], acc[m][n]);
+                            acc[m][n] = mma(wh[n], xl[m], acc[m][n]);
+                        }
+                        acc[m][n] = mma(wh[n], xh[m], acc[m][n]);
+                    }
+            }
         }
         __syncthreads();
         if (c + 1 < nchunks) stash();
@@ -547,7 +554,22 @@ hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     if (a.img && (ks != 3 || nt != 2 || a.Cin != 64 || a.mw != 32)) return hipErrorInvalidValue;
     if (a.prec != 0) {
         // reduced-precision modes exist for the 3x3 layers whose input has a multiple of 16 channels (all but conv1a)
-        if (ks != 3 || (nt != 1 && nt != 2) || a.Cin % 16 || a.prec < 1 || a.prec > 3) return hipErrorInvalidValue;
+        // and the 1x1 layers whose input has a multiple of 32 (convPb, convDb)
+        if ((ks != 1 && ks != 3) || (nt != 1 && nt != 2) || a.Cin % 16 || a.prec < 1 || a.prec > 3) return hipErrorInvalidValue;
+        if (ks == 1) {
+            // 1x1 layers: two 16-channel chunks per stage, 8 x 32 tile
+            if (a.img || a.mw != 32 || a.Cin % 32) return hipErrorInvalidValue;
+            if (nt == 2) {
+                if (a.prec == 1) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 3, false, 1, 2>), grid, block, 0, s, a);
+                else if (a.prec == 2) hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 1, false, 1, 2>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((conv_bf16_kernel<2, false, 32, 3, true, 1, 2>), grid, block, 0, s, a);
+            } else {
+                if (a.prec == 1) hipLaunchKernelGGL((conv_bf16_kernel<1, false, 32, 3, false, 1, 2>), grid, block, 0, s, a);
+                else if (a.prec == 2) hipLaunchKernelGGL((conv_bf16_kernel<1, false, 32, 1, false, 1, 2>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((conv_bf16_kernel<1, false, 32, 3, true, 1, 2>), grid, block, 0, s, a);
+            }
+            return hipGetLastError();
+        }
         if (nt == 1) {
             // 32-cout blocks (the 16 -> 16 EdgeHeatmap block): 8 x 32 tile only
             if (a.img || a.mw != 32) return hipErrorInvalidValue;
