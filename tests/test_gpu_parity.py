@@ -719,3 +719,28 @@ def test_f16_split_reports_saturation(pkg, synth, tmp_path):
     with pytest.raises(pkg.PPGError, match="range of the fp16 split"):
         ctx = pkg.Context(pkg.default_config(128, 96, weights=path, precision=3))
         ctx.extract(img)
+
+
+def test_two_cnn_lanes_equal_one(pkg, synth, monkeypatch):
+    """PPG_CNN_LANES=2 (consecutive batches alternate between two CNN streams with their own intermediates):
+    pipelined results must equal the single-lane blocking results bit for bit."""
+    H, W = 96, 128
+    seqs = [[synth.make_frame(H, W, s, t, k) for s, k in ((2, "sparse"), (9, "dense"))] for t in range(5)]
+    one = get_ctx(pkg, W, H, 500, batch=2)
+    ref = [one.extract_batch(seqs[t]) for t in range(5)]
+    monkeypatch.setenv("PPG_CNN_LANES", "2")
+    ctx = pkg.Context(pkg.default_config(W, H, max_batch=2, max_num=500))
+    monkeypatch.delenv("PPG_CNN_LANES")
+    got = []
+    for t in range(5):
+        ctx.submit_batch(seqs[t], match_prev=False)
+        if t >= 2:
+            got.append(ctx.wait_batch())
+    while len(got) < 5:
+        got.append(ctx.wait_batch())
+    for t in range(5):
+        frames = got[t][0]
+        for r, s in zip(frames, ref[t]):
+            for k in ("xy", "score", "desc", "edge_idx", "conn_idx", "coline_pairs"):
+                assert np.array_equal(r[k], s[k], equal_nan=True), (t, k)
+    ctx.close()
