@@ -744,3 +744,20 @@ def test_two_cnn_lanes_equal_one(pkg, synth, monkeypatch):
             for k in ("xy", "score", "desc", "edge_idx", "conn_idx", "coline_pairs"):
                 assert np.array_equal(r[k], s[k], equal_nan=True), (t, k)
     ctx.close()
+
+
+def test_unfused_first_layer_equals_fused(pkg, synth, monkeypatch):
+    """PPG_UNFUSED_CONV1A=1 runs conv1a as its own kernel (writing the full-resolution 64-channel tensor) instead of
+    inside conv1b's staging: the same fused-multiply-add chain, so every output is bit-identical."""
+    H, W = 72, 104
+    img = synth.make_frame(H, W, 61, 0, "dense")
+    fused = get_ctx(pkg, W, H).extract(img)
+    feat_fused = get_ctx(pkg, W, H).read_tensor(pkg.T_FEAT).copy()
+    monkeypatch.setenv("PPG_UNFUSED_CONV1A", "1")
+    ctx = pkg.Context(pkg.default_config(W, H))
+    monkeypatch.delenv("PPG_UNFUSED_CONV1A")
+    r = ctx.extract(img)
+    assert np.array_equal(ctx.read_tensor(pkg.T_FEAT), feat_fused)
+    for k in ("xy", "score", "desc", "edge_idx", "conn_idx", "coline_pairs"):
+        assert np.array_equal(r[k], fused[k], equal_nan=True), k
+    ctx.close()
