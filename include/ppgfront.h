@@ -176,6 +176,21 @@ int ppg_match_nn(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, i
                  float th, float ratio, int mode,
                  int32_t* match12, float* best, float* second, int* n_matches);
 
+/* ppg_match_nn for callers that cannot allocate.  No counterpart in the reference: it exists for code that must not
+ * call hipMalloc/hipFree — a stream under HIP graph capture, a tight serving loop, a harness that forbids allocation.
+ * It is ppg_match_nn over every B row (no candidate lists, no skipB) with inputs AND outputs in device memory of the
+ * context's GPU: dA [nA][dim], dB [nB][dim], d_match12 [nA], d_best [nA], d_second [nA], d_n_matches [1] (may be NULL
+ * in PLAIN mode).  Its work memory (the nA x nB distance matrix and the eight-nearest lists, 4.06 MiB) is a fixed
+ * device array inside the library that every GPU holds until the process ends, so nA and nB are limited to
+ * PPG_NOALLOC_MAX_ROWS (PPG_ECAP beyond that; ppg_match_nn has no such limit).  The call allocates and frees nothing.
+ * stream: a hipStream_t (as void*) to enqueue on, without waiting — or NULL: the context's own stream, and the call
+ * returns when the results are in place.  All calls on one GPU share the one work array: calls that overlap on a GPU
+ * (two contexts, two streams, two threads) race; serialise them. */
+#define PPG_NOALLOC_MAX_ROWS 1024
+int ppg_match_nn_noalloc(ppg_ctx* ctx, const float* dA, int nA, const float* dB, int nB, int dim,
+                         float th, float ratio, int mode,
+                         int32_t* d_match12, float* d_best, float* d_second, int* d_n_matches, void* stream);
+
 /* Mutual nearest neighbours, the agreement check of Matcher::SearchBySim3 (matching/src/Matcher.cpp:1316-1332): row i of
  * A takes its first argmin j among its candidates when that distance is <= th (vnMatch1, :1230-1260), row j of B takes its
  * first argmin among ITS candidates likewise (vnMatch2, :1287-1312), and match12[i] = j only if both agree.  cand12 /

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libppgfront.so")
 DEFAULT_WEIGHTS = os.path.join(_HERE, "weights", "ppg_weights.bin")
 HEADER = os.path.join(_HERE, "..", "include", "ppgfront.h")
 
-PPG_OK, PPG_EINVAL, PPG_EHIP, PPG_EIO, PPG_ENOMEM, PPG_ECAP = 0, -1, -2, -3, -4, -5
+PPG_OK, PPG_EINVAL, PPG_EHIP, PPG_EIO, PPG_ENOMEM, PPG_ECAP, PPG_ERANGE = 0, -1, -2, -3, -4, -5, -6
 T_FEAT, T_JUNC, T_HEAT_RAW, T_DESCMAP, T_SCORE, T_HEAT, T_HEAT_REFINED, T_HEAT_REMAPPED = range(8)
 MATCH_PLAIN, MATCH_INIT = 0, 1
 
@@ -259,6 +259,16 @@ class Context:
         self._chk(self.L.ppg_match_nn(C.c_void_p(self.h), _p(A), nA, _p(B), nB, 256, _p(cand_off), _p(cand_idx), _p(skipB),
                                       C.c_float(th), C.c_float(ratio), mode, _p(m), _p(best), _p(second), C.byref(cnt)))
         return m[:nA], best[:nA], second[:nA], cnt.value
+
+    def match_nn_noalloc(self, dA, nA, dB, nB, d_match12, d_best, d_second, d_count, th=0.7, ratio=0.9, mode=MATCH_PLAIN,
+                         stream=None, dim=256):
+        """ppg_match_nn_noalloc: every pointer argument is a device address (int); returns the status code."""
+        return self.L.ppg_match_nn_noalloc(C.c_void_p(self.h), C.c_void_p(dA), nA, C.c_void_p(dB), nB, dim, C.c_float(th),
+                                           C.c_float(ratio), mode, C.c_void_p(d_match12), C.c_void_p(d_best),
+                                           C.c_void_p(d_second), C.c_void_p(d_count), C.c_void_p(stream))
+
+    def last_error(self):
+        return self.L.ppg_last_error(C.c_void_p(self.h)).decode()
 
     def search_for_initialization(self, nnratio, desc1, desc2, pos2, prev_matched, window):
         desc1 = np.ascontiguousarray(desc1, np.float32).reshape(-1, 256)

@@ -29,6 +29,20 @@ namespace {
 
 thread_local std::string g_err;  // reason of a failed ppg_create (no context to hold it)
 
+// Work memory of ppg_match_nn_noalloc: the distance matrix of the largest accepted problem followed by the
+// eight-nearest lists (distances, then indices).  A file-scope device array, so that entry point never allocates;
+// every GPU the library runs on holds its own copy until the process ends.  Host code must not pass the array's
+// name to a kernel (on the host it is a stand-in, not a device address): the per-device address is looked up once
+// in scratch_setup() and kept in g_scratch_ptr.
+constexpr int kNoAllocMaxRows = PPG_NOALLOC_MAX_ROWS;
+constexpr size_t kScratchDistFloats = (size_t)kNoAllocMaxRows * kNoAllocMaxRows;
+constexpr size_t kScratchListEntries = (size_t)kNoAllocMaxRows * 8;
+constexpr size_t kScratchBytes = (kScratchDistFloats + 2 * kScratchListEntries) * 4;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+
 struct Tensor {
     std::vector<uint32_t> dims;
     std::vector<float> v;
@@ -189,6 +203,18 @@ int fail(ppg_ctx* c, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                      \
         if (e_ != hipSuccess) return fail((c), PPG_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// Looks up, once per device and with that device current, where this GPU keeps its copy of `scratch`.
+int scratch_setup(ppg_ctx* c, int dev) {
+    if (dev < 0 || dev >= kMaxDevices) return fail(c, PPG_EINVAL, "device_id %d: at most %d devices are supported", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        HIPCHK(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[dev] = p;
+    }
+    return PPG_OK;
+}
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -718,6 +744,10 @@ static int create_impl(ppg_ctx* c) {
     HIPCHK(c, hipGetDeviceProperties(&prop, f.device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, PPG_EHIP, "device %d is %s; this library is built for gfx950 only", f.device_id, prop.gcnArchName);
+    {
+        const int rc0 = scratch_setup(c, f.device_id);
+        if (rc0) return rc0;
+    }
     // the MFMA-bound CNN gets dispatch priority; the latency-bound post-processing fills what is left
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -1325,6 +1355,40 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
             *n_matches = k;
         }
     }
+    return PPG_OK;
+}
+
+int ppg_match_nn_noalloc(ppg_ctx* c, const float* dA, int nA, const float* dB, int nB, int dim, float th, float ratio,
+                         int mode, int32_t* d_match12, float* d_best, float* d_second, int* d_n_matches, void* stream) {
+    if (!c) return PPG_EINVAL;
+    if (nA < 0 || nB < 0 || dim <= 0 || dim % 16 || (mode != PPG_MATCH_PLAIN && mode != PPG_MATCH_INIT) ||
+        (nA && (!dA || !d_match12 || !d_best || !d_second)) || (nB && !dB) || (mode == PPG_MATCH_INIT && !d_n_matches))
+        return fail(c, PPG_EINVAL, "ppg_match_nn_noalloc: bad argument (dim must be a multiple of 16)");
+    if (nA > kNoAllocMaxRows || nB > kNoAllocMaxRows)
+        return fail(c, PPG_ECAP, "ppg_match_nn_noalloc: %d x %d rows exceed the fixed work memory (at most %d x %d); "
+                    "use ppg_match_nn", nA, nB, kNoAllocMaxRows, kNoAllocMaxRows);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    float* work = (float*)g_scratch_ptr[c->cfg.device_id];  // this GPU's copy, looked up at ppg_create
+    if (!work) return fail(c, PPG_EHIP, "ppg_match_nn_noalloc: the work memory of device %d was never set up", c->cfg.device_id);
+    hipStream_t s = stream ? (hipStream_t)stream : c->post;
+    if (nA > 0) {
+        // Nothing in the work memory has to start at zero: the kernels below write every distance and list entry of
+        // the nA x nB problem before they read it, and never read beyond it.
+        float* D = work;
+        float* top_d = work + kScratchDistFloats;
+        int32_t* top_i = (int32_t*)(top_d + kScratchListEntries);
+        const int ldd = std::max(nB, 1);
+        HIPCHK(c, ppg::launch_dist_matrix(dA, nA, dB, nB, dim, D, ldd, s));
+        ppg::MatchArgs m;
+        m.D = D; m.ldd = ldd; m.cand_off = nullptr; m.cand_idx = nullptr; m.skipB = nullptr; m.nA_dev = nullptr; m.nB_dev = nullptr;
+        m.nA = nA; m.nB = nB; m.th = th; m.ratio = ratio; m.topk_idx = top_i; m.topk_dist = top_d; m.claimed = nullptr;
+        m.match12 = d_match12; m.best = d_best; m.second = d_second; m.n_matches = d_n_matches;
+        if (mode == PPG_MATCH_PLAIN) HIPCHK(c, ppg::launch_match_plain(m, s));
+        else HIPCHK(c, ppg::launch_match_init(m, s));
+    } else if (mode == PPG_MATCH_INIT) {
+        HIPCHK(c, hipMemsetAsync(d_n_matches, 0, sizeof(int), s));
+    }
+    if (!stream) HIPCHK(c, hipStreamSynchronize(s));
     return PPG_OK;
 }
 
