@@ -94,6 +94,57 @@ def cpu_baseline(H, W, kind, max_num, seconds=12.0):
     return out
 
 
+def batch_sweep(pkg, synth, H, W, args, device_id):
+    """Frames/s of the pipelined step at small batches (host images, upload included) and the latency of blocking
+    single-frame calls."""
+    out = {"note": "host images in every row (upload included); pipelined = ppg_submit_batch / ppg_wait_batch four deep with "
+                   "match against the previous frame; blocking = one call at a time, results on the host before the next"}
+    scene = [synth.make_scene(H, W, 1000 * s + 11, args.kind) for s in range(16)]
+    T = 4
+    imgs = [[synth.frame_from_scene(scene[s], H, W, t) for s in range(16)] for t in range(T)]
+    rows = []
+    for B in (1, 2, 4, 8, 16):
+        ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=args.max_num, device_id=device_id,
+                                             precision=args.precision))
+        def run(first, count):
+            done = first
+            for k in range(first, first + count):
+                ctx.submit_batch(imgs[k % T][:B], match_prev=k > 0, nnratio=0.9)
+                if k - done + 1 >= 4:
+                    ctx.wait_batch(to_dict=False, want_matches=True)
+                    done += 1
+            while done < first + count:
+                ctx.wait_batch(to_dict=False, want_matches=True)
+                done += 1
+        warm = max(8, 256 // B)
+        steps = max(16, 512 // B)
+        run(0, warm)
+        t0 = time.perf_counter()
+        run(warm, steps)
+        dt = time.perf_counter() - t0
+        row = {"batch": B, "pipelined_frames_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
+        # blocking calls: ppg_extract_batch (upload, whole extract, results on the host), then the match against the
+        # previous call's frames
+        for k in range(6):
+            ctx.extract_batch(imgs[k % T][:B], to_dict=False)
+        nb = 40
+        t0 = time.perf_counter()
+        for k in range(nb):
+            ctx.extract_batch(imgs[k % T][:B], to_dict=False)
+        row["blocking_extract_ms"] = round((time.perf_counter() - t0) / nb * 1e3, 4)
+        t0 = time.perf_counter()
+        for k in range(nb):
+            ctx.extract_batch(imgs[k % T][:B], to_dict=False)
+            ctx.match_prev_batch(B, 0.9)
+        row["blocking_extract_match_ms"] = round((time.perf_counter() - t0) / nb * 1e3, 4)
+        rows.append(row)
+        ctx.close()
+    out["rows"] = rows
+    out["single_frame_latency_ms"] = {"extract": rows[0]["blocking_extract_ms"],
+                                      "extract_and_match": rows[0]["blocking_extract_match_ms"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +160,8 @@ def main():
     ap.add_argument("--precision", type=int, default=0,
                     help="0 fp32 (the parity path, the default and the number of record), 1 bf16 hi/lo split, 2 plain bf16, 3 fp16 hi/lo split")
     ap.add_argument("--host-input", action="store_true",
-                    help="hand over host buffers (upload inside the timed region): the PCIe-inclusive rate, never the headline")
+                    help="hand over host buffers in the MAIN timed region too (the default run reports that rate as with_upload)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep and the single-frame latency")
     args = ap.parse_args()
 
     import torch
@@ -224,6 +276,35 @@ def main():
     barrier()
     extract_only_fps = B * ne * world / (time.perf_counter() - t1)
 
+    # The same step with the images handed over as host buffers (PPGExtractor::run takes a cv::Mat in host memory,
+    # feature/src/PPGExtractor.cpp:151): staging into pinned memory and the upload are inside this timed region.
+    with_upload = None
+    if not args.host_input:
+        do_match[0] = True
+        args.host_input = True
+        base2 = base + 4 + ne
+        run(base2, 5)
+        barrier()
+        t3 = time.perf_counter()
+        run(base2 + 5, args.steps)
+        barrier()
+        dt3 = time.perf_counter() - t3
+        if dist is not None:
+            tt = torch.tensor([dt3], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt3 = float(tt.item())
+        args.host_input = False
+        with_upload = {"value": round(B * args.steps * world / dt3, 1), "unit": "frames/s", "steps": args.steps,
+                       "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+                       "what": "the same step with every image handed over in pageable host memory: the copy into pinned "
+                               "staging memory and the host-to-device upload are inside the timed region"}
+
+    # Batch-size sweep (rank 0's GPU only, single-GPU runs): the pipelined rate with B streams per step, and what one
+    # blocking call per frame costs (the reference's own call pattern: one image per PPGExtractor::run).
+    sweep = None
+    if world == 1 and not args.no_sweep:
+        sweep = batch_sweep(pkg, synth, H, W, args, local_rank)
+
     # Fourth pass (fp32 runs only): the same step with the 3x3 convolutions in the fp16 hi/lo-split mode
     # (ppg_config.precision = 3), reported beside the number of record, never as it.
     split = None
@@ -293,6 +374,8 @@ def main():
                          "all_convolutions_achieved": round(all_conv_tf, 2)},
             "device_ms_per_step": {k: round(v[0] / nb, 4) for k, v in prof_all.items()},
             "extract_only_frames_per_s": round(extract_only_fps, 1),
+            "with_upload": with_upload,
+            "batch_sweep": sweep,
             "f16_split_mode": split,
             "device_ms_note": f"from a second pass of {nb} steps with events around every kernel class (not the timed region)",
         }

@@ -156,7 +156,7 @@ class Context:
     def extract(self, img):
         return self.extract_batch([img])[0]
 
-    def extract_batch(self, imgs):
+    def extract_batch(self, imgs, to_dict=True):
         n = len(imgs)
         arrs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
         for a in arrs:
@@ -165,7 +165,7 @@ class Context:
         ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
         outs = (FrameOut * n)()
         self._chk(self.L.ppg_extract_batch(C.c_void_p(self.h), ptrs, n, self.W, outs))
-        return [_frame_to_dict(outs[i]) for i in range(n)]
+        return [_frame_to_dict(outs[i]) for i in range(n)] if to_dict else outs
 
     def extract_batch_device(self, dev_ptr, n, to_dict=True):
         outs = (FrameOut * n)()

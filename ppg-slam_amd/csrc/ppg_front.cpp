@@ -90,7 +90,8 @@ struct Slot {
     int32_t* h_match = nullptr;
     int* h_mcounts = nullptr;
     int* h_sat = nullptr;
-    uint8_t* h_img = nullptr;     // staging for host images
+    uint8_t* h_img = nullptr;     // pinned staging for host images
+    uint8_t* d_img = nullptr;     // device copy of the slot's host images
     std::vector<FrameHost> frames;
     std::vector<int> nkp;         // key points per frame, known after the slot was collected
     hipEvent_t done = nullptr;    // recorded behind the slot's last device-to-host copy
@@ -103,7 +104,6 @@ struct Slot {
 // lanes, so the work-groups of one batch's convolution fill the partially empty last rounds of the other's.
 struct Lane {
     hipStream_t stream = nullptr;
-    uint8_t* d_img = nullptr;
     float *a1 = nullptr, *p1 = nullptr, *a2 = nullptr, *p2 = nullptr, *a3 = nullptr, *p3 = nullptr, *a4 = nullptr,
           *feat = nullptr, *pa_o = nullptr, *da_o = nullptr, *hs0 = nullptr, *hs1 = nullptr;
 };
@@ -120,13 +120,13 @@ struct ppg_ctx {
     hipStream_t stream = nullptr;       // CNN: image upload and every convolution (alias of the current lane's)
     hipStream_t post = nullptr;         // everything after the CNN, matching, copies to the host
     hipStream_t copy_stream = nullptr;  // late copies of an already finished slot
+    hipStream_t up_stream = nullptr;    // image uploads: the copy of batch k+1 runs beside the CNN of batch k
     std::vector<void*> dev_allocs, host_allocs;
     // weights
     DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
     float *c1a_w = nullptr, *c1a_b = nullptr, *h3_w = nullptr, *h3_b = nullptr;
     float* heads_w = nullptr;  // packed weights of convPa | convDa | EdgeHeatmap block 0, concatenated
     // activations
-    uint8_t* d_img = nullptr;
     float *a1 = nullptr, *p1 = nullptr, *a2 = nullptr, *p2 = nullptr, *a3 = nullptr, *p3 = nullptr, *a4 = nullptr,
           *feat = nullptr, *pa_o = nullptr, *junc = nullptr, *da_o = nullptr, *descmap = nullptr, *hs0 = nullptr,
           *hs1 = nullptr, *hs2 = nullptr, *heat_raw = nullptr, *prob = nullptr, *refined = nullptr, *score = nullptr;
@@ -272,7 +272,7 @@ void prof_resolve(ppg_ctx* c) {
 void select_lane(ppg_ctx* c, int li) {
     Lane& l = c->lane[li];
     c->lane_cur = li;
-    c->stream = l.stream; c->d_img = l.d_img;
+    c->stream = l.stream;
     c->a1 = l.a1; c->p1 = l.p1; c->a2 = l.a2; c->p2 = l.p2; c->a3 = l.a3; c->p3 = l.p3; c->a4 = l.a4;
     c->feat = l.feat; c->pa_o = l.pa_o; c->da_o = l.da_o; c->hs0 = l.hs0; c->hs1 = l.hs1;
 }
@@ -702,6 +702,8 @@ void ppg_destroy(ppg_ctx* c) {
     for (Lane& l : c->lane)
         if (l.stream) (void)hipStreamSynchronize(l.stream);
     if (c->post) (void)hipStreamSynchronize(c->post);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
@@ -717,6 +719,7 @@ void ppg_destroy(ppg_ctx* c) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     if (c->post) (void)hipStreamDestroy(c->post);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     delete c;
 }
 
@@ -754,6 +757,8 @@ static int create_impl(ppg_ctx* c) {
     for (Lane& l : c->lane) HIPCHK(c, hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(c, hipStreamCreateWithPriority(&c->post, hipStreamNonBlocking, prio_lo));
     HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // same priority as the CNN: at a lower one the short upload kernel would starve behind every pending convolution work-group
+    HIPCHK(c, hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, prio_hi));
     {
         const char* u = getenv("PPG_UNFUSED_CONV1A");
         c->unfused_conv1a = u && atoi(u) != 0;
@@ -772,7 +777,6 @@ static int create_impl(ppg_ctx* c) {
     for (int li = 0; li < c->nlanes; li++) {
         Lane& l = c->lane[li];
 #define DL(ptr, n) do { rc = dalloc(c, &l.ptr, (n)); if (rc) return rc; } while (0)
-        DL(d_img, B * HW);
         if (c->unfused_conv1a) DL(a1, B * HW * 64);
         DL(p1, B * HW / 4 * 64);
         DL(a2, B * HW / 4 * 64);
@@ -843,6 +847,7 @@ static int create_impl(ppg_ctx* c) {
         HS(h_match, B * c->maxn);
         HS(h_mcounts, B);
         HS(h_img, B * HW);
+        DS(d_img, B * HW);
 #undef DS
 #undef HS
         HIPCHK(c, hipMemset(sl.counters, 0, sizeof(int) * 8 * B));
@@ -925,9 +930,17 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
         // still needs them to size its match rows
     }
     if (!on_device) {
+        // The upload has a stream of its own and the host waits for it here, before the convolutions are enqueued:
+        // the copy of batch k+1 then runs beside the CNN of batch k, which is still queued or running, and the CNN
+        // stream itself never waits for a copy.  The copy is a kernel reading the pinned buffer (see launch_upload).
+        // (An event wait between the two streams instead of the host wait was
+        // tried: with two batches in flight the runtime left the second copy unsubmitted until a device-wide
+        // synchronisation.)  The slot's buffers are free: a slot is reused only after its batch was waited for.
+        Slot& sl = c->slot[c->cur];
         if (imgs != c->h_img) memcpy(c->h_img, imgs, n * HW);  // pinned staging buffer of this slot
-        HIPCHK(c, hipMemcpyAsync(c->d_img, c->h_img, n * HW, hipMemcpyHostToDevice, c->stream));
-        dimg = c->d_img;
+        HIPCHK(c, ppg::launch_upload(c->h_img, sl.d_img, n * HW, c->up_stream));
+        HIPCHK(c, hipStreamSynchronize(c->up_stream));
+        dimg = sl.d_img;
     }
     if (c->cfg.precision == 3) HIPCHK(c, hipMemsetAsync(c->slot[c->cur].sat, 0, sizeof(int), c->stream));
     const int H = c->H, W = c->W;
@@ -1236,9 +1249,19 @@ static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int 
     Slot& nx = c->slot[next_slot(c->cur)];
     if (nx.inflight) return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
     const size_t HW = (size_t)c->H * c->W;
-    for (int b = 0; b < n; b++) {
+    for (int b = 0; b < n; b++)
         if (!imgs[b]) return fail(c, PPG_EINVAL, "image %d is NULL", b);
-        for (int y = 0; y < c->H; y++) memcpy(nx.h_img + b * HW + (size_t)y * c->W, imgs[b] + (size_t)y * row_stride, c->W);
+    auto copy_one = [&](int b) {
+        if (row_stride == c->W) memcpy(nx.h_img + b * HW, imgs[b], HW);
+        else
+            for (int y = 0; y < c->H; y++) memcpy(nx.h_img + b * HW + (size_t)y * c->W, imgs[b] + (size_t)y * row_stride, c->W);
+    };
+    // a batch of VGA frames is ~10 MB: spread the copy into pinned memory over the host pool
+    if (n >= 4 && c->host_threads > 1 && (size_t)n * HW >= (1u << 20)) {
+        if (!c->pool) c->pool = new HostPool(c->host_threads - 1);
+        c->pool->run(n, copy_one);
+    } else {
+        for (int b = 0; b < n; b++) copy_one(b);
     }
     *staged = nx.h_img;
     return PPG_OK;

@@ -51,6 +51,9 @@ struct Conv1aArgs {
 };
 hipError_t launch_conv1a(const Conv1aArgs& a, hipStream_t s);
 
+// Copies `bytes` (a multiple of 16, both pointers 16-byte aligned) from pinned host memory to device memory with a kernel.
+hipError_t launch_upload(const void* host_src, void* dst, size_t bytes, hipStream_t s);
+
 // ---- junction score map + non-maximum suppression ----
 struct NmsArgs {
     const float* junc;    // [B][h][w][65]

@@ -7,6 +7,7 @@
 #include "ppg_kernels.h"
 
 #include <math.h>
+#include <algorithm>
 
 namespace ppg {
 
@@ -642,6 +643,28 @@ __global__ __launch_bounds__(256) void conv1a_kernel(Conv1aArgs a) {
 hipError_t launch_conv1a(const Conv1aArgs& a, hipStream_t s) {
     const long threads = (long)a.B * a.H * a.W * 16;
     hipLaunchKernelGGL(conv1a_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Image upload by a kernel: the source is pinned host memory that the GPU reads over PCIe, 16 bytes per lane.
+// The copy engines serve a context's result copies in order, and those wait for kernels far down the pipeline;
+// an upload queued behind them would not start before the previous batch is finished.  A kernel on its own stream
+// has no such queue in front of it.
+// =====================================================================================
+typedef unsigned up_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void upload_kernel(const up_u32x4* __restrict__ src, up_u32x4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+hipError_t launch_upload(const void* host_src, void* dst, size_t bytes, hipStream_t s) {
+    if (bytes % 16 || ((uintptr_t)host_src | (uintptr_t)dst) % 16) return hipErrorInvalidValue;
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 128);
+    hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, s, (const up_u32x4*)host_src, (up_u32x4*)dst, n16);
     return hipGetLastError();
 }
 
