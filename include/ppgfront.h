@@ -331,6 +331,13 @@ int ppg_profile_read(ppg_ctx* ctx, double* ms, long long* launches);
 /* Algorithmic FLOPs (2 x MACs of the layers' shapes) enqueued per class since ppg_profile(ctx, 1); conv classes only. */
 int ppg_profile_flops(ppg_ctx* ctx, double* flops);
 
+/* Where the order-dependent tail of detectLines (feature/src/PPGExtractor.cpp:315-441) ran since ppg_create: *frames =
+ * frames collected, *host_frames = those whose tail the host statement had to redo (the device tail hands a frame over
+ * when a double-precision atan2 / sin result sits within 64 ulps of a float rounding boundary, where another libm could
+ * round the other way, or when a frame exceeds its work arrays; PPG_LINES_HOST=1 sends every frame there).  No
+ * counterpart in the reference. */
+int ppg_tail_stats(ppg_ctx* ctx, long long* frames, long long* host_frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ class Cfg(C.Structure):
                 ("junction_nms_radius", C.c_int), ("junction_max_num", C.c_uint),
                 ("line_valid_thresh", C.c_float), ("line_valid_ratio", C.c_float), ("line_dist_thresh", C.c_float),
                 ("heatmap_refine_sz", C.c_int), ("line_heatmap_thresh", C.c_float), ("line_inlier_rate", C.c_float),
-                ("stable_sort", C.c_int)]
+                ("stable_sort", C.c_int), ("math_mode", C.c_int)]
 
 
 class MapGraph(C.Structure):

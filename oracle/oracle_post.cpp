@@ -187,6 +187,7 @@ void ppgo_default_cfg(ppgo_cfg* c, int width, int height) {
     c->line_heatmap_thresh = 0.2f;
     c->line_inlier_rate = 0.8f;
     c->stable_sort = 1;
+    c->math_mode = 1;
 }
 
 int ppgo_detect_keypoints(const ppgo_cfg* c, const float* score, int32_t* kp_xy, float* kp_score,
@@ -318,6 +319,8 @@ int ppgo_detect_lines(const ppgo_cfg* c, const float* heat, int n, const float* 
     const int W = c->width, H = c->height;
     LineCtx L{c, heat, W, 1.0f / std::sqrt((float)(H * H + W * W))};
     const unsigned N = (unsigned)n;
+    const int mm = c->math_mode;
+    auto sinm = [mm](float x) -> float { return mm ? (float)std::sin((double)x) : std::sin(x); };
     std::vector<float> distMat((size_t)N * N, 0.f), dirMat((size_t)N * N, 0.f);
     auto P = [&](unsigned i, int k) { return kp_un[2 * i + k]; };
     for (unsigned i = 0; i < N; i++) {
@@ -329,7 +332,7 @@ int ppgo_detect_lines(const ppgo_cfg* c, const float* heat, int n, const float* 
             vx = vx / dist; vy = vy / dist;
             distMat[(size_t)i * N + j] = dist;
             distMat[(size_t)j * N + i] = dist;
-            float d = std::atan2(vy, vx);
+            float d = mm ? (float)std::atan2((double)vy, (double)vx) : std::atan2(vy, vx);
             dirMat[(size_t)i * N + j] = d;
             float r = (float)(d - kPi);
             if (r < -kPi) r = (float)(r + k2Pi);
@@ -349,10 +352,10 @@ int ppgo_detect_lines(const ppgo_cfg* c, const float* heat, int n, const float* 
             float ad = dirMat[(size_t)a * N + b] - dirMat[(size_t)a * N + pid_old];
             if (ad < -kPi) ad = (float)(ad + k2Pi);
             if (ad > kPi) ad = (float)(ad - k2Pi);
-            ad = std::fabs(ad);
+            ad = mm == 2 ? (float)std::abs((int)ad) : std::fabs(ad);
             if (ad > 0.2 * kPi) continue;
             float dNew = distMat[(size_t)a * N + b], dOld = distMat[(size_t)a * N + pid_old];
-            float s = std::sin(ad);
+            float s = sinm(ad);
             if (dNew <= dOld && dNew * s < c->line_dist_thresh) old.bad = true;
             if (dOld < dNew && dOld * s < c->line_dist_thresh) isOverlap = true;
         }
@@ -405,7 +408,7 @@ int ppgo_detect_lines(const ppgo_cfg* c, const float* heat, int n, const float* 
                 if (kl2.bad) continue;
                 unsigned p1 = kl1.other(p), p2 = kl2.other(p);
                 float ad = dirMat[(size_t)p * N + p1] - dirMat[(size_t)p * N + p2];
-                double pd = 0.5 * (distMat[(size_t)p * N + p1] + distMat[(size_t)p * N + p2]) * std::abs(std::sin(ad));
+                double pd = 0.5 * (distMat[(size_t)p * N + p1] + distMat[(size_t)p * N + p2]) * std::abs(sinm(ad));
                 if (minDiff > pd) { minDiff = pd; bestId = (int)i; b1 = (int)p1; b2 = (int)p2; }
             }
             if (minDiff > c->line_dist_thresh) { idx.pop_back(); continue; }

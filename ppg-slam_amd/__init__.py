@@ -310,6 +310,12 @@ class Context:
                  "lines", "descriptors")
         return {k: (ms[i], launches[i]) for i, k in enumerate(names)}
 
+    def tail_stats(self):
+        """(frames collected, frames whose line-graph tail ran on the host)."""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._chk(self.L.ppg_tail_stats(C.c_void_p(self.h), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def check_in_frustum(self, pose12, pos, normal, min_dist, max_dist, limit):
         """Frame::CheckInFrustum for m points (host arithmetic); returns in_view, proj, depth, view_cos (nan when unset)."""
         pos = np.ascontiguousarray(pos, np.float32)

@@ -137,7 +137,7 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
                     const double x = ad, x2 = x * x, lo = x - x * x2 * (1.0 / 6.0), hi = lo + x * x2 * x2 * (1.0 / 120.0);
                     if ((double)dMin * hi * (1.0 + 1e-6) < (double)distTh) close = true;
                     else if ((double)dMin * lo * (1.0 - 1e-6) > (double)distTh) close = false;
-                    else close = dMin * std::sin(ad) < distTh;
+                    else close = dMin * (float)std::sin((double)ad) < distTh;
                 }
                 if (!close) continue;
                 if (dNew <= dOld) bad[e.lid] = 1;
@@ -170,7 +170,9 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
         float vx = un[2 * cd.j] - un[2 * cd.i], vy = un[2 * cd.j + 1] - un[2 * cd.i + 1];
         cd.dist = std::sqrt(vx * vx + vy * vy);
         vx = vx / cd.dist; vy = vy / cd.dist;
-        cd.dir_ij = std::atan2(vy, vx);
+        // libm-independent statement of std::atan2(float, float): the double function rounded to float (the GPU
+        // statement of this tail, lines_resolve in ppg_kernels.hip, evaluates the same expression)
+        cd.dir_ij = (float)std::atan2((double)vy, (double)vx);
         float r = (float)(cd.dir_ij - kPi);
         if (r < -kPi) r = (float)(r + k2Pi);
         cd.dir_ji = r;
@@ -211,7 +213,7 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
                 if (bad[idx[q]]) continue;
                 const Cand& kl2 = lines[idx[q]];
                 const float ad = kl1.dir_from(p) - kl2.dir_from(p);
-                const double pd = 0.5 * (kl1.dist + kl2.dist) * std::fabs(std::sin(ad));
+                const double pd = 0.5 * (kl1.dist + kl2.dist) * std::fabs((float)std::sin((double)ad));
                 if (minDiff > pd) { minDiff = pd; bestId = (int)q; b1 = (int)kl1.other(p); b2 = (int)kl2.other(p); }
             }
             if (minDiff > cfg.line_dist_thresh) { idx.pop_back(); continue; }

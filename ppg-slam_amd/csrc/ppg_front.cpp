@@ -80,13 +80,19 @@ struct Slot {
     int* d_mcounts = nullptr;     // [B]
     int* sat = nullptr;           // precision 3: set by the convolutions when an activation saturated the fp16 split
     float *junc = nullptr, *hs2 = nullptr, *descmap = nullptr;  // CNN outputs read by the post stream
+    // line graph as the device tail leaves it (and the pinned mirrors the host reads)
+    uint32_t *edge_idx = nullptr, *conn_idx = nullptr, *coline_pairs = nullptr;
+    float* edge_score = nullptr;
+    int32_t *conn_off = nullptr, *coline_off = nullptr;
+    uint32_t *h_edge_idx = nullptr, *h_conn_idx = nullptr, *h_coline_pairs = nullptr;
+    float* h_edge_score = nullptr;
+    int32_t *h_conn_off = nullptr, *h_coline_off = nullptr;
     hipEvent_t cnn_done = nullptr;
     // pinned host mirrors
     int* h_counters = nullptr;
     int32_t* h_kp_xy = nullptr;
-    float *h_kp_score = nullptr, *h_kp_un = nullptr, *h_desc = nullptr, *h_cand_sc = nullptr;
+    float *h_kp_score = nullptr, *h_kp_un = nullptr, *h_desc = nullptr;
     uint8_t* h_kp_out = nullptr;
-    uint32_t* h_cand_ij = nullptr;
     int32_t* h_match = nullptr;
     int* h_mcounts = nullptr;
     int* h_sat = nullptr;
@@ -135,7 +141,16 @@ struct ppg_ctx {
     uint32_t *resid = nullptr, *kept = nullptr;
     unsigned long long* kept_key = nullptr;
     int* counters = nullptr;
-    int resid_cap = 0, kept_cap = 0, cand_cap = 0, cand_fast = 0;
+    int resid_cap = 0, kept_cap = 0, cand_cap = 0;
+    // work arrays of the device line-graph tail (ppg::LineTailArgs)
+    int tail_cap = 0, pair_cap = 0, edge_cap = 0;
+    float* lt_geo = nullptr;
+    int *lt_col_off = nullptr, *lt_col_cur = nullptr;
+    uint32_t *lt_col_k = nullptr, *lt_pairs = nullptr, *lt_kill = nullptr, *lt_pend = nullptr, *lt_cst = nullptr;
+    bool lines_on_host = false;           // PPG_LINES_HOST=1: every frame's tail on the host (the statement the device tail is checked against)
+    std::vector<uint32_t> fb_ij;          // host tail: one frame's candidates, fetched only for the frames that need it
+    std::vector<float> fb_sc;
+    long long tail_fallbacks = 0, tail_frames = 0;
     int32_t* kp_xy = nullptr;
     float *kp_score = nullptr, *kp_un = nullptr, *desc = nullptr;
     uint8_t* kp_out = nullptr;
@@ -148,9 +163,8 @@ struct ppg_ctx {
     uint8_t* h_img = nullptr;
     int* h_counters = nullptr;
     int32_t* h_kp_xy = nullptr;
-    float *h_kp_score = nullptr, *h_kp_un = nullptr, *h_desc = nullptr, *h_cand_sc = nullptr;
+    float *h_kp_score = nullptr, *h_kp_un = nullptr, *h_desc = nullptr;
     uint8_t* h_kp_out = nullptr;
-    uint32_t* h_cand_ij = nullptr;
     std::vector<FrameHost>* frames = nullptr;
     Slot slot[kSlots];
     int cur = 0;  // slot the alias pointers above refer to
@@ -290,7 +304,7 @@ void select_slot(ppg_ctx* c, int sidx) {
     c->counters = a.counters; c->kp_xy = a.kp_xy; c->kp_score = a.kp_score; c->kp_un = a.kp_un; c->kp_out = a.kp_out;
     c->desc = a.desc; c->cand_ij = a.cand_ij; c->cand_sc = a.cand_sc; c->d_match = a.d_match; c->d_mcounts = a.d_mcounts;
     c->h_counters = a.h_counters; c->h_kp_xy = a.h_kp_xy; c->h_kp_score = a.h_kp_score; c->h_kp_un = a.h_kp_un;
-    c->h_kp_out = a.h_kp_out; c->h_desc = a.h_desc; c->h_cand_ij = a.h_cand_ij; c->h_cand_sc = a.h_cand_sc;
+    c->h_kp_out = a.h_kp_out; c->h_desc = a.h_desc;
     c->h_match = a.h_match; c->h_mcounts = a.h_mcounts; c->frames = &a.frames; c->h_img = a.h_img;
     c->desc_prev = o.desc; c->counters_prev = o.counters;
     c->junc = a.junc; c->hs2 = a.hs2; c->descmap = a.descmap;
@@ -765,6 +779,8 @@ static int create_impl(ppg_ctx* c) {
         const char* nl = getenv("PPG_CNN_LANES");
         if (nl && atoi(nl) == 2) c->nlanes = 2;
         c->dump_tail = getenv("PPG_DUMP_TAIL");
+        const char* lh = getenv("PPG_LINES_HOST");
+        c->lines_on_host = (lh && atoi(lh) != 0) || c->dump_tail;
         const char* e = getenv("PPG_HOST_THREADS");
         int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         c->host_threads = std::max(1, std::min(t, 64));
@@ -808,13 +824,23 @@ static int create_impl(ppg_ctx* c) {
     c->resid_cap = (int)HW;
     c->kept_cap = (int)(HW / 16 + 64);
     c->cand_cap = std::max(1, c->maxn * (c->maxn - 1) / 2);
-    c->cand_fast = std::min(c->cand_cap, 32768);
+    c->edge_cap = std::max(1, std::min(c->cand_cap, 4 * c->maxn));
+    c->tail_cap = std::min(std::max(c->cand_cap, 2 * c->edge_cap + 2), 65536);
+    c->pair_cap = std::min(8 * c->tail_cap, 262144);
     DA(resid, B * c->resid_cap);
     DA(kept, B * c->kept_cap);
     DA(kept_key, B * c->kept_cap);
     DA(row_cnt, B * (c->maxn + 1));
     c->mask_words = (c->maxn + 255) / 256 * 4;
     DA(pair_mask, B * (size_t)c->maxn * c->mask_words);
+    DA(lt_geo, B * c->tail_cap * 3);
+    DA(lt_col_off, B * (c->maxn + 1));
+    DA(lt_col_cur, B * c->maxn);
+    DA(lt_col_k, B * c->tail_cap);
+    DA(lt_pairs, B * (size_t)c->pair_cap * 2);
+    DA(lt_kill, B * c->tail_cap);
+    DA(lt_pend, B * c->tail_cap);
+    DA(lt_cst, B * c->tail_cap);
     DA(mCount, 4);
     HA(h_mcount, 4);
     for (Slot& sl : c->slot) {
@@ -834,6 +860,12 @@ static int create_impl(ppg_ctx* c) {
         DS(junc, B * hw * 65);
         DS(hs2, B * HW * 4);
         DS(descmap, B * hw * 256);
+        DS(edge_idx, B * c->edge_cap * 2);
+        DS(edge_score, B * c->edge_cap);
+        DS(conn_off, B * (c->maxn + 1));
+        DS(conn_idx, B * c->edge_cap * 2);
+        DS(coline_off, B * (c->maxn + 1));
+        DS(coline_pairs, B * c->edge_cap * 2);
         HS(h_counters, B * 8);
         HS(h_sat, 1);
         sl.h_sat[0] = 0;
@@ -842,8 +874,12 @@ static int create_impl(ppg_ctx* c) {
         HS(h_kp_un, B * c->maxn * 2);
         HS(h_kp_out, B * c->maxn);
         HS(h_desc, B * c->maxn * 256);
-        HS(h_cand_ij, B * c->cand_cap);
-        HS(h_cand_sc, B * c->cand_cap * 2);
+        HS(h_edge_idx, B * c->edge_cap * 2);
+        HS(h_edge_score, B * c->edge_cap);
+        HS(h_conn_off, B * (c->maxn + 1));
+        HS(h_conn_idx, B * c->edge_cap * 2);
+        HS(h_coline_off, B * (c->maxn + 1));
+        HS(h_coline_pairs, B * c->edge_cap * 2);
         HS(h_match, B * c->maxn);
         HS(h_mcounts, B);
         HS(h_img, B * HW);
@@ -1012,6 +1048,19 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
     la.heat_thresh = c->cfg.line_heatmap_thresh;
     la.inv_scale = 1.0f / std::sqrt((float)(c->H * c->H + c->W * c->W));  // PPGExtractor.cpp:74
     HIPCHK(c, ppg::launch_line_candidates(la, c->post));
+    if (!c->lines_on_host) {
+        // overlap / score / collinearity logic of :315-441 on the device; frames it flags are redone on the host
+        Slot& sl = c->slot[c->cur];
+        ppg::LineTailArgs t;
+        t.kp_un = c->kp_un; t.counters = c->counters; t.row_off = c->row_cnt; t.cand_ij = c->cand_ij; t.cand_sc = c->cand_sc;
+        t.cand_cap = c->cand_cap; t.geo = c->lt_geo; t.col_off = c->lt_col_off; t.col_cur = c->lt_col_cur; t.col_k = c->lt_col_k;
+        t.pairs = c->lt_pairs; t.pair_cap = c->pair_cap; t.kill_t = c->lt_kill; t.pend_t = c->lt_pend; t.cst = c->lt_cst;
+        t.tail_cap = c->tail_cap; t.edge_idx = sl.edge_idx; t.edge_score = sl.edge_score; t.conn_off = sl.conn_off;
+        t.conn_idx = sl.conn_idx; t.coline_off = sl.coline_off; t.coline_pairs = sl.coline_pairs; t.edge_cap = c->edge_cap;
+        t.B = n; t.max_num = c->maxn; t.dist_thresh = c->cfg.line_dist_thresh; t.inlier_rate = c->cfg.line_inlier_rate;
+        t.heat_thresh = c->cfg.line_heatmap_thresh;
+        HIPCHK(c, ppg::launch_line_tail(t, c->post));
+    }
     return PPG_OK;
 }
 
@@ -1040,11 +1089,15 @@ static int enqueue_d2h(ppg_ctx* c, int si, int n) {
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_un, sl.kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_kp_out, sl.kp_out, (size_t)M * n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.h_desc, sl.desc, sizeof(float) * 256 * M * n, hipMemcpyDeviceToHost, s));
-    // the first cand_fast line candidates of every frame: one strided copy per array instead of one per frame
-    HIPCHK(c, hipMemcpy2DAsync(sl.h_cand_ij, sizeof(uint32_t) * c->cand_cap, sl.cand_ij, sizeof(uint32_t) * c->cand_cap,
-                               sizeof(uint32_t) * c->cand_fast, n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(sl.h_cand_sc, sizeof(float) * 2 * c->cand_cap, sl.cand_sc, sizeof(float) * 2 * c->cand_cap,
-                               sizeof(float) * 2 * c->cand_fast, n, hipMemcpyDeviceToHost, s));
+    if (!c->lines_on_host) {
+        const size_t E = c->edge_cap;
+        HIPCHK(c, hipMemcpyAsync(sl.h_edge_idx, sl.edge_idx, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_edge_score, sl.edge_score, sizeof(float) * E * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_conn_off, sl.conn_off, sizeof(int32_t) * (M + 1) * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_conn_idx, sl.conn_idx, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_coline_off, sl.coline_off, sizeof(int32_t) * (M + 1) * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_coline_pairs, sl.coline_pairs, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
+    }
     if (sl.matched) {
         HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, s));
@@ -1065,42 +1118,22 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
     if (c->prof) { c->prof_ms[PPG_PROF_HOST_WAIT] += now_ms() - t_sync0; c->prof_launches[PPG_PROF_HOST_WAIT] += 1; }
     if (c->cfg.precision == 3 && sl.h_sat[0])
         return fail(c, PPG_ERANGE, "an activation left the range of the fp16 split (|x| > 2047): use precision 0 or 1");
-    bool more = false;
     for (int b = 0; b < n; b++) {
         const int* cnt = sl.h_counters + b * 8;
         if (cnt[0] > c->resid_cap || cnt[1] > c->kept_cap || cnt[2] > c->cand_cap)
             return fail(c, PPG_ECAP, "frame %d: work list overflow (resid %d kept %d cand %d)", b, cnt[0], cnt[1], cnt[2]);
-        if (cnt[2] > c->cand_fast) {  // rare: more line candidates than the fixed-size first copy holds
-            more = true;
-            const size_t o = (size_t)b * c->cand_cap + c->cand_fast;
-            const size_t extra = (size_t)cnt[2] - c->cand_fast;
-            HIPCHK(c, hipMemcpyAsync(sl.h_cand_ij + o, sl.cand_ij + o, sizeof(uint32_t) * extra, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(sl.h_cand_sc + 2 * o, sl.cand_sc + 2 * o, sizeof(float) * 2 * extra, hipMemcpyDeviceToHost, s));
-        }
     }
-    if (more) HIPCHK(c, hipStreamSynchronize(s));
     if (c->prof) prof_resolve(c);
     for (int b = 0; b < n; b++) sl.nkp[b] = sl.h_counters[b * 8 + 3];
-    if (c->dump_tail && !c->dump_tail_done && sl.h_counters[3] > 0 && sl.h_counters[2] > 0) {
-        // debugging aid (PPG_DUMP_TAIL=<file>): the first frame's input of lines_tail(), in the format that
-        // tools/bench_tail.cpp reads
-        c->dump_tail_done = true;
-        if (FILE* f = fopen(c->dump_tail, "wb")) {
-            const int32_t hdr[2] = {sl.h_counters[3], sl.h_counters[2]};
-            fwrite(hdr, 4, 2, f);
-            fwrite(sl.h_kp_un, 4, (size_t)2 * hdr[0], f);
-            fwrite(sl.h_cand_ij, 4, (size_t)hdr[1], f);
-            fwrite(sl.h_cand_sc, 4, (size_t)2 * hdr[1], f);
-            fclose(f);
-        }
-    }
     const double t_tail0 = now_ms();
-    std::vector<double> frame_ms(n, 0.0);
-    auto do_frame = [&](int b) {
-        const double tf0 = now_ms();
+    const int M1 = M + 1;
+    // Frames whose line graph the device tail finished point straight into the pinned mirrors.  The others (a value
+    // too close to a rounding boundary, a work array too small, or PPG_LINES_HOST) get the host statement of the
+    // tail, lines_tail(), on their candidate list, which is fetched only now.
+    std::vector<int> redo;
+    for (int b = 0; b < n; b++) {
         const int* cnt = sl.h_counters + b * 8;
-        const int N = cnt[3], nc = cnt[2];
-        FrameHost& fh = sl.frames[b];
+        const int N = cnt[3];
         ppg_frame_out& o = outs[b];
         o.n = N;
         o.kp_xy = sl.h_kp_xy + (size_t)b * M * 2;
@@ -1108,17 +1141,55 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
         o.kp_un = sl.h_kp_un + (size_t)b * M * 2;
         o.kp_out = sl.h_kp_out + (size_t)b * M;
         o.desc = sl.h_desc + (size_t)b * M * 256;
+        if (N > 0 && (c->lines_on_host || cnt[5] != 0)) { redo.push_back(b); continue; }
+        FrameHost& fh = sl.frames[b];
         if (N == 0) {
             // PPGExtractor.cpp:239-240 returns before touching mvKeyEdges (stale edges of the previous
             // frame stay in the reference's member); with no key points they index nothing, so this
             // boundary reports an empty graph.
-            fh.edge_idx.clear(); fh.edge_score.clear(); fh.conn_idx.clear(); fh.coline_pairs.clear();
             fh.conn_off.assign(1, 0);
             fh.coline_off.assign(1, 0);
-        } else {
-            lines_tail(c->cfg, N, o.kp_un, sl.h_cand_ij + (size_t)b * c->cand_cap,
-                       sl.h_cand_sc + (size_t)b * c->cand_cap * 2, nc, fh, c->tails[b]);
+            o.n_edges = 0;
+            o.edge_idx = nullptr; o.edge_score = nullptr; o.conn_idx = nullptr; o.coline_pairs = nullptr;
+            o.conn_off = fh.conn_off.data(); o.coline_off = fh.coline_off.data();
+            continue;
         }
+        o.n_edges = cnt[4];
+        o.edge_idx = sl.h_edge_idx + (size_t)b * c->edge_cap * 2;
+        o.edge_score = sl.h_edge_score + (size_t)b * c->edge_cap;
+        o.conn_off = sl.h_conn_off + (size_t)b * M1;
+        o.conn_idx = sl.h_conn_idx + (size_t)b * c->edge_cap * 2;
+        o.coline_off = sl.h_coline_off + (size_t)b * M1;
+        o.coline_pairs = sl.h_coline_pairs + (size_t)b * c->edge_cap * 2;
+    }
+    c->tail_frames += n;
+    c->tail_fallbacks += (long long)redo.size();
+    for (int b : redo) {
+        const int* cnt = sl.h_counters + b * 8;
+        const int N = cnt[3], nc = cnt[2];
+        c->fb_ij.resize((size_t)std::max(nc, 1));
+        c->fb_sc.resize((size_t)std::max(nc, 1) * 2);
+        if (nc > 0) {
+            HIPCHK(c, hipMemcpyAsync(c->fb_ij.data(), sl.cand_ij + (size_t)b * c->cand_cap, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->fb_sc.data(), sl.cand_sc + (size_t)b * c->cand_cap * 2, sizeof(float) * 2 * nc, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
+        ppg_frame_out& o = outs[b];
+        if (c->dump_tail && !c->dump_tail_done && nc > 0) {
+            // debugging aid (PPG_DUMP_TAIL=<file>): the first frame's input of lines_tail(), in the format that
+            // tools/bench_tail.cpp reads
+            c->dump_tail_done = true;
+            if (FILE* f = fopen(c->dump_tail, "wb")) {
+                const int32_t hdr[2] = {N, nc};
+                fwrite(hdr, 4, 2, f);
+                fwrite(o.kp_un, 4, (size_t)2 * N, f);
+                fwrite(c->fb_ij.data(), 4, (size_t)nc, f);
+                fwrite(c->fb_sc.data(), 4, (size_t)2 * nc, f);
+                fclose(f);
+            }
+        }
+        FrameHost& fh = sl.frames[b];
+        lines_tail(c->cfg, N, o.kp_un, c->fb_ij.data(), c->fb_sc.data(), nc, fh, c->tails[b]);
         o.n_edges = (int)fh.edge_score.size();
         o.edge_idx = fh.edge_idx.data();
         o.edge_score = fh.edge_score.data();
@@ -1126,21 +1197,12 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
         o.conn_idx = fh.conn_idx.data();
         o.coline_off = fh.coline_off.data();
         o.coline_pairs = fh.coline_pairs.data();
-        frame_ms[b] = now_ms() - tf0;
-    };
-    // frames are independent: spread the order-dependent tails over host threads
-    const int nthreads = std::max(1, std::min(n, c->host_threads));
-    if (nthreads == 1) {
-        for (int b = 0; b < n; b++) do_frame(b);
-    } else {
-        if (!c->pool) c->pool = new HostPool(c->host_threads - 1);
-        c->pool->run(n, do_frame);
     }
+    const int redone = (int)redo.size();
     if (c->prof) {
         c->prof_ms[PPG_PROF_HOST_TAIL] += now_ms() - t_tail0;
         c->prof_launches[PPG_PROF_HOST_TAIL] += 1;
-        for (int b = 0; b < n; b++) c->prof_ms[PPG_PROF_HOST_TAIL_FRAMES] += frame_ms[b];
-        c->prof_launches[PPG_PROF_HOST_TAIL_FRAMES] += n;
+        c->prof_launches[PPG_PROF_HOST_TAIL_FRAMES] += redone;   // frames the host had to redo
     }
     return PPG_OK;
 }
@@ -1812,6 +1874,13 @@ int ppg_profile(ppg_ctx* c, int enable) {
     if (!c) return PPG_EINVAL;
     c->prof = enable == 2 ? 2 : (enable != 0);
     for (int k = 0; k < PPG_PROF_N; k++) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_flops[k] = 0; }
+    return PPG_OK;
+}
+
+int ppg_tail_stats(ppg_ctx* c, long long* frames, long long* host_frames) {
+    if (!c || !frames || !host_frames) return PPG_EINVAL;
+    *frames = c->tail_frames;
+    *host_frames = c->tail_fallbacks;
     return PPG_OK;
 }
 

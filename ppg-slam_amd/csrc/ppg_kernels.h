@@ -122,6 +122,39 @@ struct LineArgs {
 };
 hipError_t launch_line_candidates(const LineArgs& a, hipStream_t s);
 
+// ---- order-dependent tail of detectLines on the device (feature/src/PPGExtractor.cpp:315-441) ----
+// Flags a frame's counters[5] may carry afterwards; any of them sends the frame to the host statement of the tail.
+enum LineTailFlag { LT_GUARD = 1,   // a double-precision atan2 / sin result sat too close to a float rounding boundary
+                    LT_CAP = 2 };   // more candidates, interacting pairs, edges or incident lines than the work arrays hold
+struct LineTailArgs {
+    const float* kp_un;       // [B][max_num][2]
+    int* counters;            // [B][8]: 2 candidates, 3 key points (in); 4 edges, 5 LineTailFlag bits (out); 6 interacting pairs (work)
+    const int* row_off;       // [B][max_num+1] first candidate of every row i (LineArgs::row_cnt after the scan)
+    const uint32_t* cand_ij;  // [B][cand_cap]
+    const float* cand_sc;     // [B][cand_cap][2]
+    int cand_cap;
+    float* geo;               // [B][tail_cap][3] work: length, direction seen from i, direction seen from j
+    int* col_off;             // [B][max_num+1] work: candidates per second end point j, then their exclusive offsets
+    int* col_cur;             // [B][max_num] work
+    uint32_t* col_k;          // [B][tail_cap] work: candidate indices grouped by j
+    uint32_t* pairs;          // [B][pair_cap][2] work: (later candidate, earlier candidate | end point << 30 | code << 31)
+    int pair_cap;
+    uint32_t* kill_t;         // [B][tail_cap] work
+    uint32_t* pend_t;         // [B][tail_cap] work
+    uint32_t* cst;            // [B][tail_cap] work: state bits per candidate
+    int tail_cap;             // >= 2 * edge_cap + 2
+    uint32_t* edge_idx;       // [B][edge_cap][2]
+    float* edge_score;        // [B][edge_cap]
+    int32_t* conn_off;        // [B][max_num+1]
+    uint32_t* conn_idx;       // [B][2*edge_cap]
+    int32_t* coline_off;      // [B][max_num+1]
+    uint32_t* coline_pairs;   // [B][edge_cap][2]
+    int edge_cap;
+    int B, max_num;
+    float dist_thresh, inlier_rate, heat_thresh;
+};
+hipError_t launch_line_tail(const LineTailArgs& a, hipStream_t s);
+
 // ---- descriptor sampling + L2 normalisation ----
 struct DescArgs {
     const float* descmap;  // [B][h][w][256]

@@ -1444,6 +1444,434 @@ hipError_t launch_line_candidates(const LineArgs& a, hipStream_t s) {
 }
 
 // =====================================================================================
+// detectLines, order-dependent part (feature/src/PPGExtractor.cpp:315-441), on the device.
+//
+// The reference walks the probe survivors in (i, j) order; each new line is tested against the live lines at its
+// two end points (angle within 0.2*pi and lateral offset below LINE_DISTTHRESH): the shorter of the two wins, a
+// killed line stays dead, a rejected line is never listed.  Whether two candidates interact, and which one would
+// win, depends on geometry alone; only "is the partner alive at that moment" depends on the order.  So:
+//   line_geo_kernel     per candidate: length and the two directions (the reference's distMat / dirMat entries)
+//   line_col_*          candidates grouped by their second end point j (lists at end point j)
+//   line_inter_kernel   every (candidate, earlier candidate at a shared end point) pair is classified once, in
+//                       parallel; the few that interact (about 1.5 %) are listed
+//   line_resolve_kernel one work-group per frame: the sequential pass is the unique solution of
+//                         rejected_at_i(c) = some listed partner at i that beats c is alive when c arrives
+//                         accepted(c)      = not rejected at i and not rejected at j
+//                         alive(y, t)      = accepted(y) and no earlier-than-t candidate attempted to kill y
+//                         z attempts its kills at i always, its kills at j only if it was not rejected at i
+//                       whose dependencies all point back in time; it is found by relaxation with three-valued
+//                       states (a handful of rounds: every round settles at least the earliest open candidate).
+//                       The same work-group then applies the score thresholds (:367-389), compacts the edges in
+//                       candidate order, builds the per-point lists and pairs collinear lines (:392-432).
+// Arithmetic: every float expression is the one of the host statement (lines_tail.h); atan2 and sin are the double
+// functions rounded to float, and a result within 64 double ulps of a float rounding boundary raises LT_GUARD, upon
+// which the host statement (whose libm may round that value the other way) decides the frame instead.
+// =====================================================================================
+constexpr double kPiD = 3.1415926535897932384626433832795, k2PiD = 6.283185307179586476925286766559;
+constexpr uint32_t LT_INF = 0xFFFFFFFFu;
+// candidate state bits
+constexpr uint32_t CS_HAS_RI = 1, CS_HAS_RJ = 2, CS_RI_KNOWN = 4, CS_RI = 8, CS_ACC_KNOWN = 16, CS_ACC = 32,
+                   CS_AI_T = 64, CS_AI_U = 128, CS_AJ_T = 256, CS_AJ_U = 512;
+
+// (float)v, and whether v is so close to the midpoint of two floats that another libm's last-bit error could round it
+// the other way
+__device__ inline float round_guarded(double v, bool& risky) {
+    const float f = (float)v;
+    if (f != 0.f) {
+        int ex;
+        (void)frexp((double)f, &ex);                    // |f| in [2^(ex-1), 2^ex): float spacing 2^(ex-24) above f
+        double half = ldexp(1.0, ex - 25);
+        if ((__float_as_uint(f) & 0x7FFFFFu) == 0u && fabs(v) < fabs((double)f)) half *= 0.5;  // below a power of two
+        const double e = fabs(v - (double)f);
+        if (half - e < ldexp(1.0, ex - 47)) risky = true;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256) void line_geo_kernel(LineTailArgs a) {
+    const int b = blockIdx.y;
+    int* cnt = a.counters + b * 8;
+    const int nc = cnt[2];
+    if (nc > a.tail_cap) return;
+    const float* un = a.kp_un + (size_t)b * a.max_num * 2;
+    const uint32_t* cij = a.cand_ij + (size_t)b * a.cand_cap;
+    float* geo = a.geo + (size_t)b * a.tail_cap * 3;
+    int* colc = a.col_off + (size_t)b * (a.max_num + 1);
+    bool risky = false;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < nc; k += gridDim.x * 256) {
+        const uint32_t ij = cij[k];
+        const int i = ij >> 16, j = ij & 0xFFFFu;
+        float vx = un[2 * j] - un[2 * i], vy = un[2 * j + 1] - un[2 * i + 1];   // :278-283
+        const float dist = __fsqrt_rn(vx * vx + vy * vy);
+        vx = vx / dist; vy = vy / dist;
+        const float dij = round_guarded(atan2((double)vy, (double)vx), risky);
+        float r = (float)((double)dij - kPiD);                                   // :284-286
+        if ((double)r < -kPiD) r = (float)((double)r + k2PiD);
+        geo[3 * k] = dist; geo[3 * k + 1] = dij; geo[3 * k + 2] = r;
+        a.cst[(size_t)b * a.tail_cap + k] = 0u;
+        a.kill_t[(size_t)b * a.tail_cap + k] = LT_INF;
+        atomicAdd(&colc[j], 1);
+    }
+    if (risky) atomicOr(&cnt[5], LT_GUARD);
+}
+
+// exclusive scan of arr[0..n) in place by a 1024-thread work-group; returns the total (part: 1024 ints of LDS)
+__device__ inline int block_scan_1024(int* arr, int n, int* part) {
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    int local = 0;
+    for (int k = 0; k < per; k++) {
+        const int r = tid * per + k;
+        if (r < n) local += arr[r];
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - local;
+    for (int k = 0; k < per; k++) {
+        const int r = tid * per + k;
+        if (r < n) { const int c = arr[r]; arr[r] = run; run += c; }
+    }
+    const int total = part[1023];
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void line_col_scan_kernel(LineTailArgs a) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x;
+    int* cnt = a.counters + b * 8;
+    if (cnt[2] > a.tail_cap) {
+        if (threadIdx.x == 0) atomicOr(&cnt[5], LT_CAP);
+        return;
+    }
+    const int n = cnt[3];
+    int* col = a.col_off + (size_t)b * (a.max_num + 1);
+    const int total = block_scan_1024(col, n, part);
+    if (threadIdx.x == 0) col[n] = total;
+    for (int p = threadIdx.x; p < n; p += 1024) a.col_cur[(size_t)b * a.max_num + p] = 0;
+}
+
+__global__ __launch_bounds__(256) void line_col_fill_kernel(LineTailArgs a) {
+    const int b = blockIdx.y;
+    const int* cnt = a.counters + b * 8;
+    const int nc = cnt[2];
+    if (nc > a.tail_cap) return;
+    const uint32_t* cij = a.cand_ij + (size_t)b * a.cand_cap;
+    const int* col = a.col_off + (size_t)b * (a.max_num + 1);
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < nc; k += gridDim.x * 256) {
+        const int j = cij[k] & 0xFFFFu;
+        const int pos = atomicAdd(&a.col_cur[(size_t)b * a.max_num + j], 1);
+        a.col_k[(size_t)b * a.tail_cap + col[j] + pos] = (uint32_t)k;   // order inside a column is immaterial
+    }
+}
+
+// Does the new line (direction dn, length ln at the shared end point) interact with the listed one (dy, ly)?
+// 0 no, 1 the new line kills the listed one (:331-332), 2 the listed one rejects the new line (:333-334).
+// The body is the one of lines_tail.h's walk.
+__device__ inline int line_interaction(float dn, float ln, float dy, float ly, float distTh, bool& risky) {
+    float ad = dn - dy;
+    if ((double)ad < -kPiD) ad = (float)((double)ad + k2PiD);
+    if ((double)ad > kPiD) ad = (float)((double)ad - k2PiD);
+    ad = fabsf(ad);
+    if ((double)ad > 0.2 * kPiD) return 0;
+    const float dMin = ln <= ly ? ln : ly;
+    const float pa = dMin * ad;
+    bool close;
+    if (pa * 0.93f > distTh) close = false;
+    else if (pa * 1.00001f < distTh) close = true;
+    else {
+        const double x = ad, x2 = x * x, lo = x - x * x2 * (1.0 / 6.0), hi = lo + x * x2 * x2 * (1.0 / 120.0);
+        if ((double)dMin * hi * (1.0 + 1e-6) < (double)distTh) close = true;
+        else if ((double)dMin * lo * (1.0 - 1e-6) > (double)distTh) close = false;
+        else close = dMin * round_guarded(sin((double)ad), risky) < distTh;
+    }
+    if (!close) return 0;
+    return ln <= ly ? 1 : 2;
+}
+
+// sixteen lanes per candidate c = (i, j): its partners are the candidates listed at i (second end point i: earlier
+// rows), the earlier candidates of its own row (first end point i), and the earlier candidates listed at j
+__global__ __launch_bounds__(256) void line_inter_kernel(LineTailArgs a) {
+    const int b = blockIdx.y;
+    int* cnt = a.counters + b * 8;
+    const int nc = cnt[2];
+    if (nc > a.tail_cap) return;
+    const uint32_t* cij = a.cand_ij + (size_t)b * a.cand_cap;
+    const float* geo = a.geo + (size_t)b * a.tail_cap * 3;
+    const int* col = a.col_off + (size_t)b * (a.max_num + 1);
+    const uint32_t* colk = a.col_k + (size_t)b * a.tail_cap;
+    const int* rowoff = a.row_off + (size_t)b * (a.max_num + 1);
+    uint32_t* cst = a.cst + (size_t)b * a.tail_cap;
+    uint32_t* pairs = a.pairs + (size_t)b * a.pair_cap * 2;
+    const int gl = threadIdx.x & 15;
+    bool risky = false, full = false;
+    for (int k = (blockIdx.x * 256 + threadIdx.x) >> 4; k < nc; k += gridDim.x * 16) {
+        const uint32_t ij = cij[k];
+        const int i = ij >> 16, j = ij & 0xFFFFu;
+        const float ln = geo[3 * k], dni = geo[3 * k + 1], dnj = geo[3 * k + 2];
+        const int a0 = col[i], nA = col[i + 1] - a0;
+        const int r0 = rowoff[i], nB = k - r0;
+        const int c0 = col[j], nC = col[j + 1] - c0;
+        const int total = nA + nB + nC;
+        for (int t = gl; t < total; t += 16) {
+            int y, ep;
+            float dy;
+            if (t < nA) { y = (int)colk[a0 + t]; ep = 0; dy = geo[3 * y + 2]; }
+            else if (t < nA + nB) { y = r0 + (t - nA); ep = 0; dy = geo[3 * y + 1]; }
+            else {
+                y = (int)colk[c0 + (t - nA - nB)];
+                if (y >= k) continue;   // a later row's line at j: not there yet when c arrives
+                ep = 1; dy = geo[3 * y + 2];
+            }
+            const int code = line_interaction(ep ? dnj : dni, ln, dy, geo[3 * y], a.dist_thresh, risky);
+            if (code == 0) continue;
+            const int slot = atomicAdd(&cnt[6], 1);
+            if (slot >= a.pair_cap) { full = true; continue; }
+            pairs[2 * slot] = (uint32_t)k;
+            pairs[2 * slot + 1] = (uint32_t)y | ((uint32_t)ep << 30) | ((uint32_t)(code == 1) << 31);
+            if (code == 2) atomicOr(&cst[k], ep ? CS_HAS_RJ : CS_HAS_RI);
+        }
+    }
+    if (risky) atomicOr(&cnt[5], LT_GUARD);
+    if (full) atomicOr(&cnt[5], LT_CAP);
+}
+
+constexpr int LT_MAXPTS = 4096;   // junction_max_num limit of the library
+constexpr int LT_MAXDEG = 32;     // incident surviving lines per point the collinearity search holds in registers
+
+__global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
+    __shared__ int deg[LT_MAXPTS + 1];
+    __shared__ int cur[LT_MAXPTS + 1];
+    __shared__ int part[1024];
+    __shared__ int wtot[16];
+    __shared__ int s_flag;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* cnt = a.counters + b * 8;
+    const int n = cnt[3], nc = cnt[2];
+    int32_t* conn_off = a.conn_off + (size_t)b * (a.max_num + 1);
+    int32_t* coline_off = a.coline_off + (size_t)b * (a.max_num + 1);
+    if (n == 0 || nc == 0) {
+        // PPGExtractor.cpp:239-240 returns early without key points; without candidates every list is empty
+        for (int p = tid; p <= n; p += 1024) { conn_off[p] = 0; coline_off[p] = 0; }
+        if (tid == 0) cnt[4] = 0;
+        return;
+    }
+    if (nc > a.tail_cap || cnt[5] != 0) return;   // the host decides this frame (flags are complete: earlier kernels)
+    const int np = min(cnt[6], a.pair_cap);
+    const uint32_t* cij = a.cand_ij + (size_t)b * a.cand_cap;
+    const float* csc = a.cand_sc + (size_t)b * a.cand_cap * 2;
+    const float* geo = a.geo + (size_t)b * a.tail_cap * 3;
+    const uint32_t* pairs = a.pairs + (size_t)b * a.pair_cap * 2;
+    uint32_t* cst = a.cst + (size_t)b * a.tail_cap;
+    uint32_t* kill_t = a.kill_t + (size_t)b * a.tail_cap;
+    uint32_t* pend_t = a.pend_t + (size_t)b * a.tail_cap;
+    if (tid == 0) s_flag = 0;
+
+    // ---- the sequential overlap pass as a relaxation ----
+    for (int k = tid; k < nc; k += 1024) {
+        uint32_t s = cst[k] & (CS_HAS_RI | CS_HAS_RJ);
+        if (!(s & CS_HAS_RI)) s |= CS_RI_KNOWN;                                    // nothing at i can reject it
+        if (!(s & (CS_HAS_RI | CS_HAS_RJ))) s |= CS_ACC_KNOWN | CS_ACC;
+        cst[k] = s;
+    }
+    for (int p = tid; p < np; p += 1024) {   // kills at the first end point are attempted whatever happens to c (:316-335)
+        const uint32_t w = pairs[2 * p + 1];
+        if ((w >> 31) && !((w >> 30) & 1u)) atomicMin(&kill_t[w & 0xFFFFu], pairs[2 * p]);
+    }
+    __syncthreads();
+    for (int round = 0; round <= nc; round++) {
+        for (int k = tid; k < nc; k += 1024) pend_t[k] = LT_INF;
+        __syncthreads();
+        for (int p = tid; p < np; p += 1024) {   // kills at the second end point happen only if c got past the first (:336-337)
+            const uint32_t w = pairs[2 * p + 1];
+            if (!((w >> 31) && ((w >> 30) & 1u))) continue;
+            const uint32_t c = pairs[2 * p], s = cst[c];
+            if (s & CS_RI_KNOWN) { if (!(s & CS_RI)) atomicMin(&kill_t[w & 0xFFFFu], c); }
+            else atomicMin(&pend_t[w & 0xFFFFu], c);
+        }
+        __syncthreads();
+        for (int p = tid; p < np; p += 1024) {   // is the partner that would reject c alive when c arrives?
+            const uint32_t w = pairs[2 * p + 1];
+            if (w >> 31) continue;
+            const uint32_t c = pairs[2 * p], s = cst[c], ep = (w >> 30) & 1u, y = w & 0xFFFFu;
+            if (s & CS_ACC_KNOWN) continue;
+            if (!ep && (s & CS_RI_KNOWN)) continue;
+            const uint32_t sy = cst[y];
+            uint32_t bit;
+            if (((sy & CS_ACC_KNOWN) && !(sy & CS_ACC)) || kill_t[y] < c) continue;             // dead or never listed
+            if ((sy & CS_ACC_KNOWN) && pend_t[y] > c) bit = ep ? CS_AJ_T : CS_AI_T;               // alive
+            else bit = ep ? CS_AJ_U : CS_AI_U;                                                    // not settled yet
+            atomicOr(&cst[c], bit);
+        }
+        __syncthreads();
+        int open = 0;
+        for (int k = tid; k < nc; k += 1024) {
+            uint32_t s = cst[k];
+            if (s & CS_ACC_KNOWN) continue;
+            if (!(s & CS_RI_KNOWN)) {
+                if (s & CS_AI_T) s |= CS_RI_KNOWN | CS_RI | CS_ACC_KNOWN;        // rejected at i: never listed
+                else if (!(s & CS_AI_U)) s |= CS_RI_KNOWN;
+            }
+            if ((s & CS_RI_KNOWN) && !(s & CS_RI) && !(s & CS_ACC_KNOWN)) {
+                if (s & CS_AJ_T) s |= CS_ACC_KNOWN;
+                else if (!(s & CS_AJ_U)) s |= CS_ACC_KNOWN | CS_ACC;
+            }
+            s &= ~(CS_AI_T | CS_AI_U | CS_AJ_T | CS_AJ_U);
+            cst[k] = s;
+            open += !(s & CS_ACC_KNOWN);
+        }
+        if (__syncthreads_count(open) == 0) break;
+    }
+    // the last round's second-end-point kills of candidates settled in that round
+    for (int p = tid; p < np; p += 1024) {
+        const uint32_t w = pairs[2 * p + 1];
+        if (!((w >> 31) && ((w >> 30) & 1u))) continue;
+        const uint32_t c = pairs[2 * p], s = cst[c];
+        if ((s & CS_RI_KNOWN) && !(s & CS_RI)) atomicMin(&kill_t[w & 0xFFFFu], c);
+    }
+    for (int p = tid; p <= n; p += 1024) deg[p] = 0;
+    __syncthreads();
+
+    // ---- score thresholds (:367-389) and ordered compaction (:433-441) ----
+    uint32_t* e2k = pend_t;   // edge -> candidate (pend_t is free now; e <= k, and a chunk is read before it is written)
+    int ebase = 0;
+    for (int base = 0; base < nc; base += 1024) {
+        const int k = base + tid;
+        bool keep = false;
+        float inl = 0.f, sh = 0.f;
+        uint32_t ij = 0;
+        if (k < nc) {
+            const uint32_t s = cst[k];
+            keep = (s & CS_ACC) && kill_t[k] == LT_INF;
+            if (keep) {
+                inl = csc[2 * k]; sh = csc[2 * k + 1];
+                if (inl < a.inlier_rate) keep = false;
+                else if (sh < a.heat_thresh) keep = false;
+                ij = cij[k];
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wtot[wave] = __popcll(m);
+        __syncthreads();
+        int off = ebase, tot = 0;
+        for (int w = 0; w < 16; w++) { if (w < wave) off += wtot[w]; tot += wtot[w]; }
+        if (keep) {
+            const int e = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (e < a.edge_cap) {
+                a.edge_idx[((size_t)b * a.edge_cap + e) * 2] = ij >> 16;
+                a.edge_idx[((size_t)b * a.edge_cap + e) * 2 + 1] = ij & 0xFFFFu;
+                a.edge_score[(size_t)b * a.edge_cap + e] = inl * sh;
+                e2k[e] = (uint32_t)k;
+                atomicAdd(&deg[ij >> 16], 1);
+                atomicAdd(&deg[ij & 0xFFFFu], 1);
+            }
+        }
+        ebase += tot;
+        __syncthreads();
+    }
+    const int E = ebase;
+    if (E > a.edge_cap) {
+        if (tid == 0) atomicOr(&cnt[5], LT_CAP);
+        return;
+    }
+    // ---- per-point lists of edge ids, ascending (KeyPointEx::mvConnected) ----
+    for (int p = tid; p < n; p += 1024) cur[p] = 0;
+    (void)block_scan_1024(deg, n, part);
+    if (tid == 0) deg[n] = 2 * E;
+    __syncthreads();
+    for (int p = tid; p <= n; p += 1024) conn_off[p] = deg[p];
+    uint32_t* conn = a.conn_idx + (size_t)b * a.edge_cap * 2;
+    const uint32_t* eidx = a.edge_idx + (size_t)b * a.edge_cap * 2;
+    for (int e = tid; e < E; e += 1024) {
+        const int i = eidx[2 * e], j = eidx[2 * e + 1];
+        conn[deg[i] + atomicAdd(&cur[i], 1)] = (uint32_t)e;
+        conn[deg[j] + atomicAdd(&cur[j], 1)] = (uint32_t)e;
+    }
+    __syncthreads();
+    // ---- per point: sort its list, then the collinearity search (:392-432) ----
+    uint32_t* ctmp = kill_t;   // pairs of point p at (deg[p] / 2 ...): at most half its degree
+    bool risky = false;
+    for (int p = tid; p < n; p += 1024) {
+        const int o = deg[p], d = deg[p + 1] - o;
+        for (int x = 1; x < d; x++) {   // insertion sort (lists are short)
+            const uint32_t v = conn[o + x];
+            int y = x - 1;
+            while (y >= 0 && conn[o + y] > v) { conn[o + y + 1] = conn[o + y]; y--; }
+            conn[o + y + 1] = v;
+        }
+        int npair = 0;
+        if (d > LT_MAXDEG) { atomicOr(&s_flag, 1); }
+        else if (d >= 2) {
+            uint32_t idx[LT_MAXDEG];
+            for (int x = 0; x < d; x++) idx[x] = conn[o + x];
+            int sz = d;
+            auto dir_from = [&](uint32_t e) { const uint32_t k = e2k[e]; return (int)eidx[2 * e] == p ? geo[3 * k + 1] : geo[3 * k + 2]; };
+            auto other = [&](uint32_t e) { return (int)eidx[2 * e] == p ? eidx[2 * e + 1] : eidx[2 * e]; };
+            while (sz > 1) {
+                double minDiff = 1e9;
+                int bestId = -1;
+                uint32_t b1 = 0, b2 = 0;
+                const uint32_t e1 = idx[sz - 1];
+                const float d1 = geo[3 * e2k[e1]], dir1 = dir_from(e1);
+                for (int q = 0; q + 1 < sz; q++) {
+                    const uint32_t e2 = idx[q];
+                    const float ad = dir1 - dir_from(e2);
+                    const float sn = round_guarded(sin((double)ad), risky);
+                    const double pd = 0.5 * (double)(d1 + geo[3 * e2k[e2]]) * (double)fabsf(sn);
+                    if (minDiff > pd) { minDiff = pd; bestId = q; b1 = other(e1); b2 = other(e2); }
+                }
+                if (minDiff > (double)a.dist_thresh) { sz--; continue; }
+                ctmp[2 * (o / 2 + npair)] = b1;
+                ctmp[2 * (o / 2 + npair) + 1] = b2;
+                npair++;
+                sz--;
+                idx[bestId] = idx[sz - 1];
+                sz--;
+            }
+        }
+        cur[p] = npair;
+    }
+    __syncthreads();
+    if (risky) atomicOr(&s_flag, 2);
+    __syncthreads();
+    if (s_flag) {
+        if (tid == 0) atomicOr(&cnt[5], (s_flag & 1 ? LT_CAP : 0) | (s_flag & 2 ? LT_GUARD : 0));
+        return;
+    }
+    const int npairs = block_scan_1024(cur, n, part);
+    if (tid == 0) cur[n] = npairs;
+    __syncthreads();
+    uint32_t* cpairs = a.coline_pairs + (size_t)b * a.edge_cap * 2;
+    for (int p = tid; p <= n; p += 1024) coline_off[p] = cur[p];
+    for (int p = tid; p < n; p += 1024) {
+        const int cnum = cur[p + 1] - cur[p], src = deg[p] / 2;
+        for (int x = 0; x < cnum; x++) {
+            cpairs[2 * (cur[p] + x)] = ctmp[2 * (src + x)];
+            cpairs[2 * (cur[p] + x) + 1] = ctmp[2 * (src + x) + 1];
+        }
+    }
+    if (tid == 0) cnt[4] = E;
+}
+
+hipError_t launch_line_tail(const LineTailArgs& a, hipStream_t s) {
+    if (a.max_num > LT_MAXPTS || a.tail_cap > 65536 || a.tail_cap < 2 * a.edge_cap + 2) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(a.col_off, 0, sizeof(int) * (size_t)a.B * (a.max_num + 1), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(line_geo_kernel, dim3(32, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(line_col_scan_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(line_col_fill_kernel, dim3(32, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(line_inter_kernel, dim3(256, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(line_resolve_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
 // genPointDescriptor (feature/src/PPGExtractor.cpp:515-538): grid_sampler(bilinear, zeros,
 // align_corners=false) of the raw descriptor map at the integer key-point positions, then
 // F::normalize(dim=1).  One wave per key point, four channels per lane (1 KiB coalesced per tap).

@@ -761,3 +761,29 @@ def test_unfused_first_layer_equals_fused(pkg, synth, monkeypatch):
     for k in ("xy", "score", "desc", "edge_idx", "conn_idx", "coline_pairs"):
         assert np.array_equal(r[k], fused[k], equal_nan=True), k
     ctx.close()
+
+
+def test_device_line_tail_equals_host_statement(pkg, synth, monkeypatch, capsys):
+    """The order-dependent tail of detectLines runs on the device (relaxation of the sequential overlap pass, score
+    thresholds, compaction, collinearity); PPG_LINES_HOST=1 runs the host statement instead.  Both must give the same
+    graph bit for bit, and the device must keep all but a few frames (it hands a frame to the host only when a libm
+    result sits at a float rounding boundary or a work array overflows)."""
+    H, W = 480, 640
+    imgs = [synth.make_frame(H, W, 800 + k, k % 3, "dense" if k % 2 else "sparse") for k in range(8)]
+    dev = get_ctx(pkg, W, H, 1024, batch=8)
+    f0, h0 = dev.tail_stats()
+    got = dev.extract_batch(imgs)
+    f1, h1 = dev.tail_stats()
+    monkeypatch.setenv("PPG_LINES_HOST", "1")
+    host = pkg.Context(pkg.default_config(W, H, max_batch=8, max_num=1024))
+    monkeypatch.delenv("PPG_LINES_HOST")
+    ref = host.extract_batch(imgs)
+    assert host.tail_stats() == (16, 8)   # the warm-up batch has no key points; the 8 real frames ran on the host
+    host.close()
+    for r, s in zip(got, ref):
+        assert r["n_edges"] == s["n_edges"] > 20
+        for k in ("edge_idx", "edge_score", "conn_off", "conn_idx", "coline_off", "coline_pairs"):
+            assert np.array_equal(r[k], s[k], equal_nan=True), k
+    with capsys.disabled():
+        print(f"\ndevice line tail: {h1 - h0} of {f1 - f0} frames handed to the host")
+    assert f1 - f0 == 8 and h1 - h0 <= 2
