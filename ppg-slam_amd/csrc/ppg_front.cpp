@@ -193,6 +193,10 @@ struct ppg_ctx {
     DBuf<int32_t> mOff, mIdx, mMatch, mTopI;
     DBuf<uint8_t> mSkip;
     DBuf<uint32_t> mClaim;
+    DBuf<float> mNorm;
+    DBuf<int32_t> mListCnt;
+    DBuf<uint16_t> mListCol;
+    bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
     int* mCount = nullptr;
     int* h_mcount = nullptr;
     int* h_mcounts = nullptr;    // alias of the current slot's
@@ -721,7 +725,7 @@ void ppg_destroy(ppg_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
-                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p};
+                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p};
     for (void* p : ms)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_all) (void)hipEventDestroy(e);
@@ -779,6 +783,8 @@ static int create_impl(ppg_ctx* c) {
         const char* nl = getenv("PPG_CNN_LANES");
         if (nl && atoi(nl) == 2) c->nlanes = 2;
         c->dump_tail = getenv("PPG_DUMP_TAIL");
+        const char* mm = getenv("PPG_MATCH_MATRIX");
+        c->match_matrix = mm && atoi(mm) != 0;
         const char* lh = getenv("PPG_LINES_HOST");
         c->lines_on_host = (lh && atoi(lh) != 0) || c->dump_tail;
         const char* e = getenv("PPG_HOST_THREADS");
@@ -1393,9 +1399,24 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
         for (size_t k = 0; k < nd; k++)
             if (cand_idx[k] < 0 || cand_idx[k] >= nB) return fail(c, PPG_EINVAL, "cand_idx[%zu] out of range", k);
     }
+    // All-pairs claim matching of rows of norm <= 1 (what genPointDescriptor produces) takes the path without a
+    // distance matrix; everything else (candidate lists, skip flags, longer rows, other dimensions) the general one.
+    bool fused = !csr && mode == PPG_MATCH_INIT && dim == 256 && !skipB && nA <= 1024 && nB >= 1 && nB <= 1024 && !c->match_matrix;
+    auto norms_ok = [dim](const float* X, int n) {
+        for (int i = 0; i < n; i++) {
+            float s2 = 0.f;
+            for (int d = 0; d < dim; d++) s2 += X[(size_t)i * dim + d] * X[(size_t)i * dim + d];
+            if (!(s2 <= 1.0001f)) return false;
+        }
+        return true;
+    };
+    fused = fused && norms_ok(A, nA) && norms_ok(B, nB);
     int rc = grow(c, c->mA, (size_t)nA * dim);
     if (!rc) rc = grow(c, c->mB, (size_t)std::max(nB, 1) * dim);
-    if (!rc) rc = grow(c, c->mD, std::max<size_t>(nd, 1));
+    if (!rc && !fused) rc = grow(c, c->mD, std::max<size_t>(nd, 1));
+    if (!rc && fused) rc = grow(c, c->mNorm, (size_t)2 * std::max(nA, nB));
+    if (!rc && fused) rc = grow(c, c->mListCnt, (size_t)std::max(nA, nB));
+    if (!rc && fused) rc = grow(c, c->mListCol, (size_t)std::max(nA, nB) * 64);
     if (!rc) rc = grow(c, c->mMatch, nA);
     if (!rc) rc = grow(c, c->mBest, nA);
     if (!rc) rc = grow(c, c->mSecond, nA);
@@ -1408,7 +1429,15 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     HIPCHK(c, hipMemcpyAsync(c->mA.p, A, sizeof(float) * nA * dim, hipMemcpyHostToDevice, s));
     if (nB) HIPCHK(c, hipMemcpyAsync(c->mB.p, B, sizeof(float) * nB * dim, hipMemcpyHostToDevice, s));
     if (skipB && nB) HIPCHK(c, hipMemcpyAsync(c->mSkip.p, skipB, nB, hipMemcpyHostToDevice, s));
-    if (csr) {
+    if (fused) {
+        ppg::FusedMatchArgs f;
+        f.A = c->mA.p; f.B = c->mB.p; f.sA = 0; f.sB = 0; f.nA_dev = nullptr; f.nB_dev = nullptr; f.sn = 0; f.nA = nA; f.nB = nB;
+        f.maxn = std::max(nA, nB); f.batch = 1; f.th = th; f.ratio = ratio;
+        f.norm_work = c->mNorm.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
+        f.topk_idx = c->mTopI.p; f.topk_dist = c->mTopD.p; f.match12 = c->mMatch.p; f.best = c->mBest.p; f.second = c->mSecond.p;
+        f.n_matches = c->mCount;
+        HIPCHK(c, ppg::launch_match_fused(f, s));
+    } else if (csr) {
         HIPCHK(c, hipMemcpyAsync(c->mOff.p, cand_off, sizeof(int32_t) * (nA + 1), hipMemcpyHostToDevice, s));
         if (nd) HIPCHK(c, hipMemcpyAsync(c->mIdx.p, cand_idx, sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
         HIPCHK(c, ppg::launch_dist_csr(c->mA.p, nA, c->mB.p, dim, c->mOff.p, c->mIdx.p, c->mD.p, s));
@@ -1425,7 +1454,8 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
         for (int i = 0; i < nA; i++) { match12[i] = -1; if (best) best[i] = 1e6f; if (second) second[i] = 1e6f; }
         return PPG_OK;
     }
-    if (mode == PPG_MATCH_PLAIN) HIPCHK(c, ppg::launch_match_plain(m, s));
+    if (fused) { /* enqueued above */ }
+    else if (mode == PPG_MATCH_PLAIN) HIPCHK(c, ppg::launch_match_plain(m, s));
     else HIPCHK(c, ppg::launch_match_init(m, s));
     HIPCHK(c, hipMemcpyAsync(match12, c->mMatch.p, sizeof(int32_t) * nA, hipMemcpyDeviceToHost, s));
     if (best) HIPCHK(c, hipMemcpyAsync(best, c->mBest.p, sizeof(float) * nA, hipMemcpyDeviceToHost, s));
@@ -1807,14 +1837,29 @@ int ppg_search_for_initialization(ppg_ctx* c, float nnratio, const float* desc1,
 static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const float* dB, const int* nB, int batch,
                           float nnratio, int32_t* d_match, int* d_mcounts) {
     const int M = c->maxn;
-    int rc = grow(c, c->mD, (size_t)M * M * batch);
-    if (!rc) rc = grow(c, c->mBest, (size_t)M * batch);
+    const bool fused = M <= 1024 && !c->match_matrix;
+    int rc = grow(c, c->mBest, (size_t)M * batch);
     if (!rc) rc = grow(c, c->mSecond, (size_t)M * batch);
     if (!rc) rc = grow(c, c->mTopD, (size_t)M * 8 * batch + 64);
     if (!rc) rc = grow(c, c->mTopI, (size_t)M * 8 * batch + 64);
+    if (!rc && !fused) rc = grow(c, c->mD, (size_t)M * M * batch);
+    if (!rc && fused) rc = grow(c, c->mNorm, (size_t)2 * M * batch);
+    if (!rc && fused) rc = grow(c, c->mListCnt, (size_t)M * batch);
+    if (!rc && fused) rc = grow(c, c->mListCol, (size_t)M * batch * 64);
     if (rc) return rc;
     hipStream_t s = c->post;
     ProfScope ps(c, PPG_PROF_MATCH, c->post);
+    if (fused) {
+        // descriptors out of desc_sample_kernel have norm 1 (or are all zero), which the prefilter's margin assumes
+        ppg::FusedMatchArgs f;
+        f.A = dA; f.B = dB; f.sA = (size_t)M * 256; f.sB = (size_t)M * 256; f.nA_dev = nA; f.nB_dev = nB; f.sn = 8;
+        f.maxn = M; f.batch = batch; f.th = 0.7f /* TH_LOW, Matcher.cpp:13 */; f.ratio = nnratio;
+        f.norm_work = c->mNorm.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
+        f.topk_idx = c->mTopI.p; f.topk_dist = c->mTopD.p; f.match12 = d_match; f.best = c->mBest.p; f.second = c->mSecond.p;
+        f.n_matches = d_mcounts;
+        HIPCHK(c, ppg::launch_match_fused(f, s));
+        return PPG_OK;
+    }
     HIPCHK(c, ppg::launch_dist_matrix_batched(dA, nA, M, (size_t)M * 256, dB, nB, M, (size_t)M * 256, 256, c->mD.p, M,
                                               (size_t)M * M, 8, batch, s));
     ppg::MatchArgs m;

@@ -200,6 +200,25 @@ struct MatchArgs {
     int bs_n = 0;
 };
 hipError_t launch_match_plain(const MatchArgs& a, hipStream_t s);
+
+// All-pairs SearchForInitialization for `batch` independent problems of unit-norm (or all-zero) 256-float rows without
+// a distance matrix: MFMA prefilter, exact chain for the listed columns, claim pass as a fixed point.  maxn <= 1024.
+struct FusedMatchArgs {
+    const float* A; const float* B;       // problem b: A + b*sA (rows nA_dev[b*sn]), B + b*sB (rows nB_dev[b*sn])
+    size_t sA, sB;
+    const int* nA_dev; const int* nB_dev; int sn;   // device-resident row counts, or both nullptr: nA, nB below (batch 1)
+    int nA = 0, nB = 0;
+    int maxn, batch;
+    float th, ratio;
+    float* norm_work;                     // [2][batch][maxn] work
+    int* list_cnt;                        // [batch][maxn] work
+    uint16_t* list_col;                   // [batch][maxn][64] work
+    int32_t* topk_idx; float* topk_dist;  // [batch][maxn][8] work
+    int32_t* match12;                     // [batch][maxn]
+    float* best; float* second;           // [batch][maxn] or both nullptr
+    int* n_matches;                       // [batch]
+};
+hipError_t launch_match_fused(const FusedMatchArgs& a, hipStream_t s);
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s);
 
 }  // namespace ppg

@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(256) void line_score_kernel(LineArgs a) {
         // ps = start (i), pe = end (j)
         const float psx = un[2 * i], psy = un[2 * i + 1], pex = un[2 * j], pey = un[2 * j + 1];
         const float dx = psx - pex, dy = psy - pey;
-        const float dist = __fsqrt_rn(dx * dx + dy * dy);
+        const float dist = sqrtf(dx * dx + dy * dy);
         const int lenLevel = (int)((double)(dist * a.inv_scale) * 4.0);
         const int segNum = live ? (int)(dist * kInvSampleGap[lenLevel < 0 ? 0 : (lenLevel > 3 ? 3 : lenLevel)]) : 0;
         const float step = (float)(1.0 / (double)(float)segNum);
@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(256) void line_geo_kernel(LineTailArgs a) {
         const uint32_t ij = cij[k];
         const int i = ij >> 16, j = ij & 0xFFFFu;
         float vx = un[2 * j] - un[2 * i], vy = un[2 * j + 1] - un[2 * i + 1];   // :278-283
-        const float dist = __fsqrt_rn(vx * vx + vy * vy);
+        const float dist = sqrtf(vx * vx + vy * vy);
         vx = vx / dist; vy = vy / dist;
         const float dij = round_guarded(atan2((double)vy, (double)vx), risky);
         float r = (float)((double)dij - kPiD);                                   // :284-286
@@ -1977,7 +1977,7 @@ __global__ __launch_bounds__(256) void dist_matrix_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int r = r0 + tr * 4 + i, c = c0 + tc * 4 + j;
-            if (r < nA && c < nB) D[(size_t)r * ldd + c] = __fsqrt_rn(acc[i][j]);
+            if (r < nA && c < nB) D[(size_t)r * ldd + c] = sqrtf(acc[i][j]);
         }
 }
 
@@ -2016,7 +2016,7 @@ __global__ __launch_bounds__(256) void dist_csr_kernel(const float* __restrict__
                 acc = fmaf(t, t, acc);
             }
         }
-        Dc[k] = __fsqrt_rn(acc);
+        Dc[k] = sqrtf(acc);
     }
 }
 
@@ -2247,6 +2247,360 @@ hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(match_topk_kernel, dim3((rows + 3) / 4, a.batch), dim3(256), 0, s, a);
     hipLaunchKernelGGL(match_init_resolve_kernel, dim3(a.batch), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// All-pairs SearchForInitialization (matching/src/Matcher.cpp:591-644) without the distance matrix.
+//
+// Every distance the reference's loop can ask for is DescriptorDistance = one fused-multiply-add chain over the 256
+// components; evaluating it for all pairs is 2 x 256 VALU operations per pair on the issue port the convolutions'
+// MFMAs share.  Only the few nearest columns of a row can ever become its best or second-best match, so:
+//   row_norm_kernel        |row|^2 of every descriptor
+//   match_prefilter_kernel |a|^2 + |b|^2 - 2 a.b for all pairs on the fp32 MFMA (one v_mfma_f32_32x32x2 per 2048
+//                          products instead of 4096 VALU operations), kept in registers, never written: per row a
+//                          bound T on its 8th smallest value, and the columns within T + margin are listed.  The
+//                          margin covers the rounding of both evaluations (|approx - chain| <= 1.2e-4 for rows of
+//                          norm <= 1), so the list holds the 8 columns that are nearest by the exact chain.
+//   match_exact_kernel     the exact chain for the listed columns only (about 10 per row), sorted: the same
+//                          eight-nearest lists match_topk_kernel makes from the full matrix
+//   match_jacobi_kernel    the sequential claim pass as a fixed point: given a guess of every row's match, each row
+//                          recomputes its own from the claims of the rows before it; the system is triangular, so
+//                          a guess that reproduces itself is the sequential result (rows 0..t-1 are final after
+//                          round t; in practice a handful of rounds).
+// =====================================================================================
+constexpr int PF_ROWS = 32, PF_MAXCOLS = 1024, PF_LIST = 64;
+constexpr float PF_MARGIN = 3.0e-4f;
+
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ X, const int* n_dev, int sn, int maxn, size_t sX,
+                                                       float* __restrict__ out, int n_host) {
+    const int b = blockIdx.y;
+    const int n = n_dev ? min(maxn, n_dev[b * sn]) : n_host;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const f32x4 v = *(const f32x4*)(X + b * sX + (size_t)row * 256 + lane * 4);
+    float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)b * maxn + row] = s;
+}
+
+// order-preserving map of float bit patterns to unsigned
+__device__ inline uint32_t fkey(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float fkey_inv(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+struct PrefilterArgs {
+    const float* A; const float* B;        // [batch][maxn][256]
+    size_t sA, sB;
+    const int* nA_dev; const int* nB_dev; int sn;   // row counts on the device, or nullptr: nA / nB below
+    int nA, nB;
+    const float* normA; const float* normB;  // [batch][maxn]
+    int maxn;
+    int* list_cnt;                         // [batch][maxn]
+    uint16_t* list_col;                    // [batch][maxn][PF_LIST]
+};
+
+__global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[PF_ROWS][260];
+    __shared__ float nas[PF_ROWS];
+    __shared__ uint32_t gmin[PF_ROWS][32];
+    __shared__ float thr[PF_ROWS];
+    __shared__ int lcount[PF_ROWS];
+    __shared__ uint16_t llist[PF_ROWS][PF_LIST];
+    const int b = blockIdx.y, r0 = blockIdx.x * PF_ROWS;
+    const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
+    if (r0 >= nA) return;
+    const float* A = a.A + b * a.sA;
+    const float* B = a.B + b * a.sB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    for (int idx = tid; idx < PF_ROWS * 64; idx += 256) {
+        const int r = idx >> 6, c4 = idx & 63;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < nA) v = *(const f32x4*)(A + (size_t)(r0 + r) * 256 + c4 * 4);
+        *(f32x4*)&As[r][c4 * 4] = v;
+    }
+    if (tid < PF_ROWS) {
+        nas[tid] = r0 + tid < nA ? a.normA[(size_t)b * a.maxn + r0 + tid] : 0.f;
+        lcount[tid] = 0;
+    }
+    for (int idx = tid; idx < PF_ROWS * 32; idx += 256) gmin[idx >> 5][idx & 31] = 0xFFFFFFFFu;
+    __syncthreads();
+    const int ntiles = (nB + 31) / 32;
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+    // lane (li, lh) supplies, for the e-th MFMA of step t, component 8t + 4*lh + e of its row (A) / column (B)
+    const float* brow[8];
+    bool bval[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = (wave + 4 * q) * 32 + li;
+        bval[q] = col < nB;
+        brow[q] = B + (size_t)(bval[q] ? col : 0) * 256 + 4 * lh;
+    }
+    for (int t = 0; t < 32; t++) {
+        const f32x4 av = *(const f32x4*)&As[li][8 * t + 4 * lh];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (wave + 4 * q >= ntiles) continue;   // uniform per wave
+            f32x4 bv = *(const f32x4*)(brow[q] + 8 * t);
+            if (!bval[q]) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[q], 0, 0, 0);
+        }
+    }
+    // approx = |a|^2 + |b|^2 - 2 a.b; lane holds column li of each of its tiles and rows (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (wave + 4 * q >= ntiles) continue;
+        const int col = (wave + 4 * q) * 32 + li;
+        const float nb = bval[q] ? a.normB[(size_t)b * a.maxn + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            acc[q][r] = bval[q] ? (nas[row] + nb) - 2.f * acc[q][r] : 3.0e38f;
+        }
+    }
+    // T(row) = 8th smallest of the 32 per-lane-column minima: at least 8 different columns lie at or below it
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float m = 3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (wave + 4 * q < ntiles) m = fminf(m, acc[q][r]);
+        atomicMin(&gmin[(r & 3) + 8 * (r >> 2) + 4 * lh][li], fkey(m));
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 8; rr++) {
+        const int row = wave * 8 + rr;
+        const uint32_t mine = gmin[row][li];
+        int rank = 0;
+#pragma unroll
+        for (int o = 0; o < 32; o++) {
+            const uint32_t other = __shfl(mine, o);
+            rank += (other < mine) || (other == mine && o < li);
+        }
+        if (rank == 7 && lh == 0) {
+            const float T = fkey_inv(mine);
+            thr[row] = T < 1.0e38f ? T + PF_MARGIN : 3.0e38f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (wave + 4 * q >= ntiles || !bval[q]) continue;
+        const int col = (wave + 4 * q) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (acc[q][r] <= thr[row]) {
+                const int slot = atomicAdd(&lcount[row], 1);
+                if (slot < PF_LIST) llist[row][slot] = (uint16_t)col;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < PF_ROWS * PF_LIST; idx += 256) {
+        const int r = idx / PF_LIST, sidx = idx % PF_LIST;
+        if (r0 + r < nA && sidx < min(lcount[r], PF_LIST))
+            a.list_col[((size_t)b * a.maxn + r0 + r) * PF_LIST + sidx] = llist[r][sidx];
+    }
+    if (tid < PF_ROWS && r0 + tid < nA) a.list_cnt[(size_t)b * a.maxn + r0 + tid] = lcount[tid];
+}
+
+__device__ inline float chain_distance(const float* __restrict__ x, const float* __restrict__ y) {
+    float acc = 0.f;
+    for (int d = 0; d < 256; d += 4) {
+        const f32x4 u = *(const f32x4*)(x + d), v = *(const f32x4*)(y + d);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float t = u[q] - v[q];
+            acc = fmaf(t, t, acc);
+        }
+    }
+    return sqrtf(acc);
+}
+
+// one wave per row: exact distances of the listed columns (or of every column when the list overflowed), then the
+// 8 nearest by (distance, column) — the lists match_topk_kernel produces
+__global__ __launch_bounds__(256) void match_exact_kernel(PrefilterArgs a, int32_t* topk_idx, float* topk_dist) {
+    const int b = blockIdx.y;
+    const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nA) return;
+    const float* x = a.A + b * a.sA + (size_t)row * 256;
+    const float* B = a.B + b * a.sB;
+    const int cnt = a.list_cnt[(size_t)b * a.maxn + row];
+    float ld[TOPK];
+    int lp[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) { ld[t] = 3e38f; lp[t] = 0x7FFFFFFF; }
+    auto insert = [&](float d, int p) {
+#pragma unroll
+        for (int t = 0; t < TOPK; t++)
+            if (d < ld[t] || (d == ld[t] && p < lp[t])) {
+                const float td = ld[t]; const int tp = lp[t];
+                ld[t] = d; lp[t] = p; d = td; p = tp;
+            }
+    };
+    if (cnt <= PF_LIST) {
+        if (lane < cnt) {
+            const int col = a.list_col[((size_t)b * a.maxn + row) * PF_LIST + lane];
+            insert(chain_distance(x, B + (size_t)col * 256), col);
+        }
+    } else {
+        for (int col = lane; col < nB; col += 64) insert(chain_distance(x, B + (size_t)col * 256), col);
+    }
+    int32_t* oi = topk_idx + ((size_t)b * a.maxn + row) * TOPK;
+    float* od = topk_dist + ((size_t)b * a.maxn + row) * TOPK;
+    for (int t = 0; t < TOPK; t++) {
+        float d = ld[0];
+        int p = lp[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od2 = __shfl_xor(d, o);
+            const int op = __shfl_xor(p, o);
+            if (od2 < d || (od2 == d && op < p)) { d = od2; p = op; }
+        }
+        if (lp[0] == p && p != 0x7FFFFFFF) {
+#pragma unroll
+            for (int q = 0; q < TOPK - 1; q++) { ld[q] = ld[q + 1]; lp[q] = lp[q + 1]; }
+            ld[TOPK - 1] = 3e38f; lp[TOPK - 1] = 0x7FFFFFFF;
+        }
+        if (lane == 0) {
+            const bool valid = p != 0x7FFFFFFF;
+            od[t] = valid ? d : 3e38f;
+            oi[t] = valid ? p : -1;
+        }
+    }
+}
+
+struct JacobiArgs {
+    const float* A; const float* B; size_t sA, sB;
+    const int* nA_dev; const int* nB_dev; int sn;
+    int nA, nB;
+    int maxn;
+    const int32_t* topk_idx; const float* topk_dist;   // [batch][maxn][8]
+    float th, ratio;
+    int32_t* match12;   // [batch][maxn]
+    float* best; float* second;   // [batch][maxn] or nullptr
+    int* n_matches;     // [batch]
+};
+
+__global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
+    __shared__ uint32_t claim[4096];     // smallest row whose current guess is this column
+    __shared__ int32_t guess[4096];
+    __shared__ int fb_rows[1024];
+    __shared__ int fb_n;
+    __shared__ float rb[16], rs[16];
+    __shared__ int rp[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
+    const float* A = a.A + b * a.sA;
+    const float* B = a.B + b * a.sB;
+    const int32_t* ti = a.topk_idx + (size_t)b * a.maxn * TOPK;
+    const float* td = a.topk_dist + (size_t)b * a.maxn * TOPK;
+    for (int i = tid; i < nA; i += 1024) guess[i] = -1;
+    __syncthreads();
+    for (int round = 0; round <= nA; round++) {
+        for (int j = tid; j < nB; j += 1024) claim[j] = 0xFFFFFFFFu;
+        if (tid == 0) fb_n = 0;
+        __syncthreads();
+        for (int i = tid; i < nA; i += 1024)
+            if (guess[i] >= 0) atomicMin(&claim[guess[i]], (uint32_t)i);
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < nA; i += 1024) {
+            float best = 1e6f, second = 1e6f;
+            int bidx = -1, nfree = 0, nlisted = 0;
+#pragma unroll
+            for (int t = 0; t < TOPK; t++) {
+                const int col = ti[(size_t)i * TOPK + t];
+                if (col < 0) continue;
+                nlisted++;
+                if (claim[col] < (uint32_t)i) continue;   // claimed by an earlier row
+                const float d = td[(size_t)i * TOPK + t];
+                if (nfree == 0) { best = d; bidx = col; }
+                else if (nfree == 1) second = d;
+                nfree++;
+            }
+            if (nfree < 2 && nlisted == TOPK) {
+                // the list ran dry while the row has more candidates: its best two come from a scan of the whole row
+                fb_rows[atomicAdd(&fb_n, 1)] = i;
+                continue;
+            }
+            const int m = (bidx >= 0 && best <= a.th && best < second * a.ratio) ? bidx : -1;
+            if (a.best) { a.best[(size_t)b * a.maxn + i] = best; a.second[(size_t)b * a.maxn + i] = second; }
+            changed |= m != guess[i];
+            a.match12[(size_t)b * a.maxn + i] = m;   // guess is read by nobody else until the barrier below
+        }
+        __syncthreads();
+        const int nfb = fb_n;
+        for (int f = 0; f < nfb; f++) {   // rare; the order of these rows does not matter (all read the same claims)
+            const int i = fb_rows[f];
+            Best2 v = {1e6f, 1e6f, -1, -1};
+            for (int col = tid; col < nB; col += 1024) {
+                if (claim[col] < (uint32_t)i) continue;
+                const float d = chain_distance(A + (size_t)i * 256, B + (size_t)col * 256);
+                if (d < v.b) { v.b2 = v.b; v.b = d; v.pos = col; v.idx = col; }
+                else if (d < v.b2) v.b2 = d;
+            }
+            v = best2_wave(v);
+            if (lane == 0) { rb[wave] = v.b; rs[wave] = v.b2; rp[wave] = v.pos; }
+            __syncthreads();
+            if (tid == 0) {
+                Best2 r = {rb[0], rs[0], rp[0], rp[0]};
+                for (int w = 1; w < 16; w++) r = best2_merge(r, Best2{rb[w], rs[w], rp[w], rp[w]});
+                const int m = (r.pos >= 0 && r.b <= a.th && r.b < r.b2 * a.ratio) ? r.pos : -1;
+                if (a.best) { a.best[(size_t)b * a.maxn + i] = r.b; a.second[(size_t)b * a.maxn + i] = r.b2; }
+                if (m != guess[i]) fb_n = -1;   // marks a change
+                a.match12[(size_t)b * a.maxn + i] = m;
+            }
+            __syncthreads();
+        }
+        if (fb_n < 0) changed = 1;
+        const int any = __syncthreads_count(changed);
+        for (int i = tid; i < nA; i += 1024) guess[i] = a.match12[(size_t)b * a.maxn + i];
+        __syncthreads();
+        if (!any) break;
+    }
+    int cnt = 0;
+    for (int i = tid; i < nA; i += 1024) cnt += guess[i] >= 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) rp[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; w++) tot += rp[w];
+        a.n_matches[b] = tot;
+    }
+}
+
+hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
+    if (f.maxn > PF_MAXCOLS || f.batch < 1) return hipErrorInvalidValue;
+    PrefilterArgs p;
+    p.A = f.A; p.B = f.B; p.sA = f.sA; p.sB = f.sB; p.nA_dev = f.nA_dev; p.nB_dev = f.nB_dev; p.sn = f.sn;
+    p.nA = f.nA; p.nB = f.nB;
+    if (!f.nA_dev && (f.nA > f.maxn || f.nB > f.maxn || f.nA < 0 || f.nB < 0)) return hipErrorInvalidValue;
+    p.normA = f.norm_work; p.normB = f.norm_work + (size_t)f.batch * f.maxn; p.maxn = f.maxn;
+    p.list_cnt = f.list_cnt; p.list_col = f.list_col;
+    dim3 gn((f.maxn + 3) / 4, f.batch);
+    hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.A, f.nA_dev, f.sn, f.maxn, f.sA, f.norm_work, f.nA);
+    hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.maxn, f.sB, f.norm_work + (size_t)f.batch * f.maxn, f.nB);
+    hipLaunchKernelGGL(match_prefilter_kernel, dim3((f.maxn + PF_ROWS - 1) / PF_ROWS, f.batch), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(match_exact_kernel, gn, dim3(256), 0, s, p, f.topk_idx, f.topk_dist);
+    JacobiArgs j;
+    j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
+    j.nA = f.nA; j.nB = f.nB;
+    j.topk_idx = f.topk_idx; j.topk_dist = f.topk_dist; j.th = f.th; j.ratio = f.ratio; j.match12 = f.match12;
+    j.best = f.best; j.second = f.second; j.n_matches = f.n_matches;
+    hipLaunchKernelGGL(match_jacobi_kernel, dim3(f.batch), dim3(1024), 0, s, j);
     return hipGetLastError();
 }
 

@@ -787,3 +787,40 @@ def test_device_line_tail_equals_host_statement(pkg, synth, monkeypatch, capsys)
     with capsys.disabled():
         print(f"\ndevice line tail: {h1 - h0} of {f1 - f0} frames handed to the host")
     assert f1 - f0 == 8 and h1 - h0 <= 2
+
+
+def test_fused_match_equals_matrix_path(pkg, orc, synth, monkeypatch):
+    """Resident all-pairs SearchForInitialization: the fused path (MFMA prefilter, exact chain for the listed
+    columns, claim pass as a fixed point) against the path through the full distance matrix (PPG_MATCH_MATRIX=1)
+    and against the oracle, on real frames including few-key-point ones, bit for bit."""
+    H, W = 480, 640
+    kinds = [("dense", 1024), ("sparse", 1024)]
+    for kind, maxn in kinds:
+        seqs = [[synth.make_frame(H, W, 900 + s, t, kind) for s in range(3)] for t in range(3)]
+        # a nearly empty stream: fewer than 10 key points -> all-zero descriptors -> every distance is 0
+        blank = np.full((H, W), 128, np.uint8)
+        blank[100:140, 200:260] = 255
+        for t in range(3):
+            seqs[t].append(blank)
+        fused = get_ctx(pkg, W, H, maxn, batch=4)
+        res = []
+        for t in range(3):
+            frames = fused.extract_batch(seqs[t])
+            res.append((frames, fused.match_prev_batch(4, 0.9) if t else None))
+        monkeypatch.setenv("PPG_MATCH_MATRIX", "1")
+        ref = pkg.Context(pkg.default_config(W, H, max_batch=4, max_num=maxn))
+        monkeypatch.delenv("PPG_MATCH_MATRIX")
+        cfg = orc.default_cfg(W, H, maxn)
+        for t in range(3):
+            ref.extract_batch(seqs[t])
+            if not t:
+                continue
+            cnts_r, m_r = ref.match_prev_batch(4, 0.9)
+            cnts_f, m_f = res[t][1]
+            assert np.array_equal(cnts_f, cnts_r) and np.array_equal(m_f, m_r), (kind, t)
+            for b in (0, 3):
+                f0, f1 = res[t - 1][0][b], res[t][0][b]
+                co, mo, _ = orc.search_for_initialization(cfg, 0.9, f0["desc"], f1["desc"], f1["un"], f0["un"], 0)
+                assert cnts_f[b] == co and np.array_equal(m_f[b, :f0["n"]], mo), (kind, t, b)
+            assert cnts_f[:3].min() > 50
+        ref.close()
