@@ -194,7 +194,8 @@ struct ppg_ctx {
     DBuf<uint8_t> mSkip;
     DBuf<uint32_t> mClaim;
     DBuf<float> mNorm;
-    DBuf<int32_t> mListCnt;
+    DBuf<int32_t> mListCnt, mNearLen;
+    DBuf<float> mListRad;
     DBuf<uint16_t> mListCol;
     bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
     int* mCount = nullptr;
@@ -725,7 +726,7 @@ void ppg_destroy(ppg_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
-                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p};
+                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mNearLen.p, c->mListRad.p};
     for (void* p : ms)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_all) (void)hipEventDestroy(e);
@@ -1420,8 +1421,10 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     if (!rc) rc = grow(c, c->mMatch, nA);
     if (!rc) rc = grow(c, c->mBest, nA);
     if (!rc) rc = grow(c, c->mSecond, nA);
-    if (!rc) rc = grow(c, c->mTopD, (size_t)nA * 8 + 64);
-    if (!rc) rc = grow(c, c->mTopI, (size_t)nA * 8 + 64);
+    if (!rc) rc = grow(c, c->mTopD, (size_t)std::max(nA, nB) * 32 + 64);
+    if (!rc) rc = grow(c, c->mTopI, (size_t)std::max(nA, nB) * 32 + 64);
+    if (!rc && fused) rc = grow(c, c->mNearLen, (size_t)std::max(nA, nB));
+    if (!rc && fused) rc = grow(c, c->mListRad, (size_t)std::max(nA, nB));
     if (!rc && csr) rc = grow(c, c->mOff, (size_t)nA + 1);
     if (!rc && csr) rc = grow(c, c->mIdx, std::max<size_t>(nd, 1));
     if (!rc && skipB) rc = grow(c, c->mSkip, std::max(nB, 1));
@@ -1434,7 +1437,8 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
         f.A = c->mA.p; f.B = c->mB.p; f.sA = 0; f.sB = 0; f.nA_dev = nullptr; f.nB_dev = nullptr; f.sn = 0; f.nA = nA; f.nB = nB;
         f.maxn = std::max(nA, nB); f.batch = 1; f.th = th; f.ratio = ratio;
         f.norm_work = c->mNorm.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
-        f.topk_idx = c->mTopI.p; f.topk_dist = c->mTopD.p; f.match12 = c->mMatch.p; f.best = c->mBest.p; f.second = c->mSecond.p;
+        f.list_rad = c->mListRad.p; f.near_len = c->mNearLen.p;
+        f.near_idx = c->mTopI.p; f.near_dist = c->mTopD.p; f.match12 = c->mMatch.p; f.best = c->mBest.p; f.second = c->mSecond.p;
         f.n_matches = c->mCount;
         HIPCHK(c, ppg::launch_match_fused(f, s));
     } else if (csr) {
@@ -1840,8 +1844,10 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
     const bool fused = M <= 1024 && !c->match_matrix;
     int rc = grow(c, c->mBest, (size_t)M * batch);
     if (!rc) rc = grow(c, c->mSecond, (size_t)M * batch);
-    if (!rc) rc = grow(c, c->mTopD, (size_t)M * 8 * batch + 64);
-    if (!rc) rc = grow(c, c->mTopI, (size_t)M * 8 * batch + 64);
+    if (!rc) rc = grow(c, c->mTopD, (size_t)M * 32 * batch + 64);
+    if (!rc) rc = grow(c, c->mTopI, (size_t)M * 32 * batch + 64);
+    if (!rc && fused) rc = grow(c, c->mNearLen, (size_t)M * batch);
+    if (!rc && fused) rc = grow(c, c->mListRad, (size_t)M * batch);
     if (!rc && !fused) rc = grow(c, c->mD, (size_t)M * M * batch);
     if (!rc && fused) rc = grow(c, c->mNorm, (size_t)2 * M * batch);
     if (!rc && fused) rc = grow(c, c->mListCnt, (size_t)M * batch);
@@ -1855,7 +1861,8 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
         f.A = dA; f.B = dB; f.sA = (size_t)M * 256; f.sB = (size_t)M * 256; f.nA_dev = nA; f.nB_dev = nB; f.sn = 8;
         f.maxn = M; f.batch = batch; f.th = 0.7f /* TH_LOW, Matcher.cpp:13 */; f.ratio = nnratio;
         f.norm_work = c->mNorm.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
-        f.topk_idx = c->mTopI.p; f.topk_dist = c->mTopD.p; f.match12 = d_match; f.best = c->mBest.p; f.second = c->mSecond.p;
+        f.list_rad = c->mListRad.p; f.near_len = c->mNearLen.p;
+        f.near_idx = c->mTopI.p; f.near_dist = c->mTopD.p; f.match12 = d_match; f.best = c->mBest.p; f.second = c->mSecond.p;
         f.n_matches = d_mcounts;
         HIPCHK(c, ppg::launch_match_fused(f, s));
         return PPG_OK;

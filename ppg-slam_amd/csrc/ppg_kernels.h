@@ -213,7 +213,9 @@ struct FusedMatchArgs {
     float* norm_work;                     // [2][batch][maxn] work
     int* list_cnt;                        // [batch][maxn] work
     uint16_t* list_col;                   // [batch][maxn][64] work
-    int32_t* topk_idx; float* topk_dist;  // [batch][maxn][8] work
+    float* list_rad;                      // [batch][maxn] work
+    int32_t* near_idx; float* near_dist;  // [batch][maxn][32] work (16-byte aligned)
+    int* near_len;                        // [batch][maxn] work
     int32_t* match12;                     // [batch][maxn]
     float* best; float* second;           // [batch][maxn] or both nullptr
     int* n_matches;                       // [batch]

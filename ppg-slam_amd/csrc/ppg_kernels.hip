@@ -2270,7 +2270,12 @@ hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
 //                          round t; in practice a handful of rounds).
 // =====================================================================================
 constexpr int PF_ROWS = 32, PF_MAXCOLS = 1024, PF_LIST = 64;
-constexpr float PF_MARGIN = 3.0e-4f;
+constexpr int PF_K = 16;        // T bounds the PF_K-th smallest value of a row
+constexpr int PF_NEAR = 32;     // length of the sorted nearest lists handed to the claim pass
+// |approx - chain| <= PF_EPS for rows of norm <= 1 (three roundings of 256-term sums); the listing threshold is
+// T + PF_MARGIN with PF_MARGIN >= 2 * PF_EPS, so every column whose exact squared distance is <= T + PF_MARGIN - PF_EPS
+// is listed: up to that radius the sorted list is the true nearest-neighbour order with nothing missing.
+constexpr float PF_MARGIN = 3.0e-4f, PF_EPS = 1.2e-4f;
 
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ X, const int* n_dev, int sn, int maxn, size_t sX,
                                                        float* __restrict__ out, int n_host) {
@@ -2302,6 +2307,7 @@ struct PrefilterArgs {
     int maxn;
     int* list_cnt;                         // [batch][maxn]
     uint16_t* list_col;                    // [batch][maxn][PF_LIST]
+    float* list_rad;                       // [batch][maxn] squared radius up to which the list is complete
 };
 
 __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
@@ -2386,7 +2392,7 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
             const uint32_t other = __shfl(mine, o);
             rank += (other < mine) || (other == mine && o < li);
         }
-        if (rank == 7 && lh == 0) {
+        if (rank == PF_K - 1 && lh == 0) {
             const float T = fkey_inv(mine);
             thr[row] = T < 1.0e38f ? T + PF_MARGIN : 3.0e38f;
         }
@@ -2411,10 +2417,13 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
         if (r0 + r < nA && sidx < min(lcount[r], PF_LIST))
             a.list_col[((size_t)b * a.maxn + r0 + r) * PF_LIST + sidx] = llist[r][sidx];
     }
-    if (tid < PF_ROWS && r0 + tid < nA) a.list_cnt[(size_t)b * a.maxn + r0 + tid] = lcount[tid];
+    if (tid < PF_ROWS && r0 + tid < nA) {
+        a.list_cnt[(size_t)b * a.maxn + r0 + tid] = lcount[tid];
+        a.list_rad[(size_t)b * a.maxn + r0 + tid] = thr[tid] < 1.0e38f ? thr[tid] - PF_EPS : 3.0e38f;
+    }
 }
 
-__device__ inline float chain_distance(const float* __restrict__ x, const float* __restrict__ y) {
+__device__ inline float chain_distance2(const float* __restrict__ x, const float* __restrict__ y) {
     float acc = 0.f;
     for (int d = 0; d < 256; d += 4) {
         const f32x4 u = *(const f32x4*)(x + d), v = *(const f32x4*)(y + d);
@@ -2424,12 +2433,14 @@ __device__ inline float chain_distance(const float* __restrict__ x, const float*
             acc = fmaf(t, t, acc);
         }
     }
-    return sqrtf(acc);
+    return acc;
 }
+__device__ inline float chain_distance(const float* __restrict__ x, const float* __restrict__ y) { return sqrtf(chain_distance2(x, y)); }
 
-// one wave per row: exact distances of the listed columns (or of every column when the list overflowed), then the
-// 8 nearest by (distance, column) — the lists match_topk_kernel produces
-__global__ __launch_bounds__(256) void match_exact_kernel(PrefilterArgs a, int32_t* topk_idx, float* topk_dist) {
+// One wave per row: exact distances of the listed columns, sorted by (distance, column): near_idx/near_dist hold the
+// row's nearest columns in the order the reference's scan would rank them, near_len how many of them are certain
+// (nothing nearer is missing).  A row whose list overflowed is scanned completely (eight certain entries).
+__global__ __launch_bounds__(256) void match_exact_kernel(PrefilterArgs a, int32_t* near_idx, float* near_dist, int* near_len) {
     const int b = blockIdx.y;
     const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -2437,28 +2448,54 @@ __global__ __launch_bounds__(256) void match_exact_kernel(PrefilterArgs a, int32
     const float* x = a.A + b * a.sA + (size_t)row * 256;
     const float* B = a.B + b * a.sB;
     const int cnt = a.list_cnt[(size_t)b * a.maxn + row];
+    int32_t* oi = near_idx + ((size_t)b * a.maxn + row) * PF_NEAR;
+    float* od = near_dist + ((size_t)b * a.maxn + row) * PF_NEAR;
+    if (cnt <= PF_LIST) {
+        const float rad = a.list_rad[(size_t)b * a.maxn + row];
+        float d = 3e38f;
+        int p = 0x7FFFFFFF;
+        bool certain = false;
+        if (lane < cnt) {
+            p = a.list_col[((size_t)b * a.maxn + row) * PF_LIST + lane];
+            const float d2 = chain_distance2(x, B + (size_t)p * 256);
+            certain = d2 <= rad;
+            d = sqrtf(d2);
+        }
+        // rank of this lane's entry among the listed ones by (distance, column)
+        int rank = 0;
+        for (int o = 0; o < cnt; o++) {
+            const float od2 = __shfl(d, o);
+            const int op = __shfl(p, o);
+            rank += od2 < d || (od2 == d && op < p);
+        }
+        // entries are certain up to the first uncertain one in rank order
+        const unsigned long long unc = __ballot(lane < cnt && !certain);
+        int first_unc = cnt;
+        for (int o = 0; o < cnt; o++) {
+            const int r = __shfl(rank, o);
+            if ((unc >> o) & 1ull) first_unc = min(first_unc, r);
+        }
+        // every column of the row is listed: the list is the whole row, certain to its end
+        const int len = cnt >= nB ? cnt : first_unc;
+        if (lane < cnt && rank < PF_NEAR) { oi[rank] = p; od[rank] = d; }
+        if (lane == 0) near_len[(size_t)b * a.maxn + row] = min(len, PF_NEAR);
+        return;
+    }
     float ld[TOPK];
     int lp[TOPK];
 #pragma unroll
     for (int t = 0; t < TOPK; t++) { ld[t] = 3e38f; lp[t] = 0x7FFFFFFF; }
-    auto insert = [&](float d, int p) {
+    for (int col = lane; col < nB; col += 64) {
+        float d = chain_distance(x, B + (size_t)col * 256);
+        int p = col;
 #pragma unroll
         for (int t = 0; t < TOPK; t++)
             if (d < ld[t] || (d == ld[t] && p < lp[t])) {
                 const float td = ld[t]; const int tp = lp[t];
                 ld[t] = d; lp[t] = p; d = td; p = tp;
             }
-    };
-    if (cnt <= PF_LIST) {
-        if (lane < cnt) {
-            const int col = a.list_col[((size_t)b * a.maxn + row) * PF_LIST + lane];
-            insert(chain_distance(x, B + (size_t)col * 256), col);
-        }
-    } else {
-        for (int col = lane; col < nB; col += 64) insert(chain_distance(x, B + (size_t)col * 256), col);
     }
-    int32_t* oi = topk_idx + ((size_t)b * a.maxn + row) * TOPK;
-    float* od = topk_dist + ((size_t)b * a.maxn + row) * TOPK;
+    int len = 0;
     for (int t = 0; t < TOPK; t++) {
         float d = ld[0];
         int p = lp[0];
@@ -2473,12 +2510,12 @@ __global__ __launch_bounds__(256) void match_exact_kernel(PrefilterArgs a, int32
             for (int q = 0; q < TOPK - 1; q++) { ld[q] = ld[q + 1]; lp[q] = lp[q + 1]; }
             ld[TOPK - 1] = 3e38f; lp[TOPK - 1] = 0x7FFFFFFF;
         }
-        if (lane == 0) {
-            const bool valid = p != 0x7FFFFFFF;
-            od[t] = valid ? d : 3e38f;
-            oi[t] = valid ? p : -1;
+        if (p != 0x7FFFFFFF) {
+            if (lane == 0) { od[t] = d; oi[t] = p; }
+            len = t + 1;
         }
     }
+    if (lane == 0) near_len[(size_t)b * a.maxn + row] = len;
 }
 
 struct JacobiArgs {
@@ -2486,7 +2523,8 @@ struct JacobiArgs {
     const int* nA_dev; const int* nB_dev; int sn;
     int nA, nB;
     int maxn;
-    const int32_t* topk_idx; const float* topk_dist;   // [batch][maxn][8]
+    const int32_t* near_idx; const float* near_dist;   // [batch][maxn][PF_NEAR]
+    const int* near_len;                               // [batch][maxn]
     float th, ratio;
     int32_t* match12;   // [batch][maxn]
     float* best; float* second;   // [batch][maxn] or nullptr
@@ -2494,85 +2532,101 @@ struct JacobiArgs {
 };
 
 __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
-    __shared__ uint32_t claim[4096];     // smallest row whose current guess is this column
-    __shared__ int32_t guess[4096];
-    __shared__ int fb_rows[1024];
-    __shared__ int fb_n;
+    __shared__ uint32_t claim[PF_MAXCOLS];     // smallest row whose current guess is this column
+    __shared__ int32_t guess[PF_MAXCOLS];
+    __shared__ int fb_rows[PF_MAXCOLS];
+    __shared__ int fb_n, fb_changed;
     __shared__ float rb[16], rs[16];
     __shared__ int rp[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
     const float* A = a.A + b * a.sA;
     const float* B = a.B + b * a.sB;
-    const int32_t* ti = a.topk_idx + (size_t)b * a.maxn * TOPK;
-    const float* td = a.topk_dist + (size_t)b * a.maxn * TOPK;
-    for (int i = tid; i < nA; i += 1024) guess[i] = -1;
+    // thread i owns row i (nA <= 1024); its sorted nearest list stays in registers for every round
+    const int i = tid;
+    float nd[PF_NEAR];
+    int ni[PF_NEAR];
+    int len = 0;
+    if (i < nA) {
+        len = a.near_len[(size_t)b * a.maxn + i];
+        const f32x4* pd = (const f32x4*)(a.near_dist + ((size_t)b * a.maxn + i) * PF_NEAR);
+        const int4* pi = (const int4*)(a.near_idx + ((size_t)b * a.maxn + i) * PF_NEAR);
+#pragma unroll
+        for (int q = 0; q < PF_NEAR / 4; q++) {
+            const f32x4 dv = pd[q];
+            const int4 iv = pi[q];
+            nd[4 * q] = dv[0]; nd[4 * q + 1] = dv[1]; nd[4 * q + 2] = dv[2]; nd[4 * q + 3] = dv[3];
+            ni[4 * q] = iv.x; ni[4 * q + 1] = iv.y; ni[4 * q + 2] = iv.z; ni[4 * q + 3] = iv.w;
+        }
+        guess[i] = -1;
+    }
+    int mine = -1;
+    float mbest = 1e6f, msecond = 1e6f;
     __syncthreads();
     for (int round = 0; round <= nA; round++) {
         for (int j = tid; j < nB; j += 1024) claim[j] = 0xFFFFFFFFu;
-        if (tid == 0) fb_n = 0;
+        if (tid == 0) { fb_n = 0; fb_changed = 0; }
         __syncthreads();
-        for (int i = tid; i < nA; i += 1024)
-            if (guess[i] >= 0) atomicMin(&claim[guess[i]], (uint32_t)i);
+        if (i < nA && guess[i] >= 0) atomicMin(&claim[guess[i]], (uint32_t)i);
         __syncthreads();
         int changed = 0;
-        for (int i = tid; i < nA; i += 1024) {
+        bool fallback = false;
+        if (i < nA) {
             float best = 1e6f, second = 1e6f;
-            int bidx = -1, nfree = 0, nlisted = 0;
+            int bidx = -1, nfree = 0;
 #pragma unroll
-            for (int t = 0; t < TOPK; t++) {
-                const int col = ti[(size_t)i * TOPK + t];
-                if (col < 0) continue;
-                nlisted++;
-                if (claim[col] < (uint32_t)i) continue;   // claimed by an earlier row
-                const float d = td[(size_t)i * TOPK + t];
-                if (nfree == 0) { best = d; bidx = col; }
-                else if (nfree == 1) second = d;
+            for (int t = 0; t < PF_NEAR; t++) {
+                if (t >= len || nfree >= 2) continue;
+                if (claim[ni[t]] < (uint32_t)i) continue;   // claimed by an earlier row
+                if (nfree == 0) { best = nd[t]; bidx = ni[t]; }
+                else second = nd[t];
                 nfree++;
             }
-            if (nfree < 2 && nlisted == TOPK) {
-                // the list ran dry while the row has more candidates: its best two come from a scan of the whole row
+            if (nfree < 2 && len < nB) {
+                // the certain part of the list ran dry while the row has more columns: scan the whole row
+                fallback = true;
                 fb_rows[atomicAdd(&fb_n, 1)] = i;
-                continue;
+            } else {
+                const int m = (bidx >= 0 && best <= a.th && best < second * a.ratio) ? bidx : -1;
+                changed = m != mine;
+                mine = m; mbest = best; msecond = second;
             }
-            const int m = (bidx >= 0 && best <= a.th && best < second * a.ratio) ? bidx : -1;
-            if (a.best) { a.best[(size_t)b * a.maxn + i] = best; a.second[(size_t)b * a.maxn + i] = second; }
-            changed |= m != guess[i];
-            a.match12[(size_t)b * a.maxn + i] = m;   // guess is read by nobody else until the barrier below
         }
         __syncthreads();
         const int nfb = fb_n;
-        for (int f = 0; f < nfb; f++) {   // rare; the order of these rows does not matter (all read the same claims)
-            const int i = fb_rows[f];
+        for (int f = 0; f < nfb; f++) {   // rare; these rows all read the same claims, so their order is immaterial
+            const int r = fb_rows[f];
             Best2 v = {1e6f, 1e6f, -1, -1};
             for (int col = tid; col < nB; col += 1024) {
-                if (claim[col] < (uint32_t)i) continue;
-                const float d = chain_distance(A + (size_t)i * 256, B + (size_t)col * 256);
+                if (claim[col] < (uint32_t)r) continue;
+                const float d = chain_distance(A + (size_t)r * 256, B + (size_t)col * 256);
                 if (d < v.b) { v.b2 = v.b; v.b = d; v.pos = col; v.idx = col; }
                 else if (d < v.b2) v.b2 = d;
             }
             v = best2_wave(v);
             if (lane == 0) { rb[wave] = v.b; rs[wave] = v.b2; rp[wave] = v.pos; }
             __syncthreads();
-            if (tid == 0) {
-                Best2 r = {rb[0], rs[0], rp[0], rp[0]};
-                for (int w = 1; w < 16; w++) r = best2_merge(r, Best2{rb[w], rs[w], rp[w], rp[w]});
-                const int m = (r.pos >= 0 && r.b <= a.th && r.b < r.b2 * a.ratio) ? r.pos : -1;
-                if (a.best) { a.best[(size_t)b * a.maxn + i] = r.b; a.second[(size_t)b * a.maxn + i] = r.b2; }
-                if (m != guess[i]) fb_n = -1;   // marks a change
-                a.match12[(size_t)b * a.maxn + i] = m;
+            if (tid == r) {
+                Best2 q = {rb[0], rs[0], rp[0], rp[0]};
+                for (int w = 1; w < 16; w++) q = best2_merge(q, Best2{rb[w], rs[w], rp[w], rp[w]});
+                const int m = (q.pos >= 0 && q.b <= a.th && q.b < q.b2 * a.ratio) ? q.pos : -1;
+                if (m != mine) fb_changed = 1;
+                mine = m; mbest = q.b; msecond = q.b2;
             }
             __syncthreads();
         }
-        if (fb_n < 0) changed = 1;
-        const int any = __syncthreads_count(changed);
-        for (int i = tid; i < nA; i += 1024) guess[i] = a.match12[(size_t)b * a.maxn + i];
-        __syncthreads();
-        if (!any) break;
+        (void)fallback;
+        if (i < nA) guess[i] = mine;
+        const int fbc = fb_changed;   // read before the barrier: thread 0 clears it at the top of the next round
+        if (__syncthreads_count(changed | fbc) == 0) break;
     }
-    int cnt = 0;
-    for (int i = tid; i < nA; i += 1024) cnt += guess[i] >= 0;
+    if (i < nA) {
+        a.match12[(size_t)b * a.maxn + i] = mine;
+        if (a.best) { a.best[(size_t)b * a.maxn + i] = mbest; a.second[(size_t)b * a.maxn + i] = msecond; }
+    }
+    int cnt = (i < nA && mine >= 0) ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    __syncthreads();
     if (lane == 0) rp[wave] = cnt;
     __syncthreads();
     if (tid == 0) {
@@ -2589,16 +2643,16 @@ hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
     p.nA = f.nA; p.nB = f.nB;
     if (!f.nA_dev && (f.nA > f.maxn || f.nB > f.maxn || f.nA < 0 || f.nB < 0)) return hipErrorInvalidValue;
     p.normA = f.norm_work; p.normB = f.norm_work + (size_t)f.batch * f.maxn; p.maxn = f.maxn;
-    p.list_cnt = f.list_cnt; p.list_col = f.list_col;
+    p.list_cnt = f.list_cnt; p.list_col = f.list_col; p.list_rad = f.list_rad;
     dim3 gn((f.maxn + 3) / 4, f.batch);
     hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.A, f.nA_dev, f.sn, f.maxn, f.sA, f.norm_work, f.nA);
     hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.maxn, f.sB, f.norm_work + (size_t)f.batch * f.maxn, f.nB);
     hipLaunchKernelGGL(match_prefilter_kernel, dim3((f.maxn + PF_ROWS - 1) / PF_ROWS, f.batch), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(match_exact_kernel, gn, dim3(256), 0, s, p, f.topk_idx, f.topk_dist);
+    hipLaunchKernelGGL(match_exact_kernel, gn, dim3(256), 0, s, p, f.near_idx, f.near_dist, f.near_len);
     JacobiArgs j;
     j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
     j.nA = f.nA; j.nB = f.nB;
-    j.topk_idx = f.topk_idx; j.topk_dist = f.topk_dist; j.th = f.th; j.ratio = f.ratio; j.match12 = f.match12;
+    j.near_idx = f.near_idx; j.near_dist = f.near_dist; j.near_len = f.near_len; j.th = f.th; j.ratio = f.ratio; j.match12 = f.match12;
     j.best = f.best; j.second = f.second; j.n_matches = f.n_matches;
     hipLaunchKernelGGL(match_jacobi_kernel, dim3(f.batch), dim3(1024), 0, s, j);
     return hipGetLastError();
