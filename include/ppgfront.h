@@ -113,10 +113,13 @@ int ppg_extract_batch_device(ppg_ctx* ctx, const uint8_t* d_imgs, int n, ppg_fra
  * waiting.  ppg_wait_batch blocks until the OLDEST submitted batch is on the host, finishes its line
  * graphs and fills outs (and matches12: n rows of junction_max_num entries; n_matches: n counts; both
  * optional).  It returns the batch's frame count (> 0) or a negative error.  At most four batches may be
- * in flight; the buffers behind `outs` stay valid until the fourth submit after this wait.
+ * in flight.  The buffers behind `outs` belong to a ring of five slots: they survive the first ppg_submit_batch*
+ * after this wait and are overwritten by the second one (with fewer batches in flight they live longer; never rely on
+ * more than that one submit).
  * No counterpart in the reference (PPGExtractor::run blocks, PPGExtractor.cpp:125). */
 int ppg_submit_batch_device(ppg_ctx* ctx, const uint8_t* d_imgs, int n, int match_prev, float nnratio);
-/* The same for host images (copied to pinned staging memory before the call returns). */
+/* The same for host images: they are copied to pinned staging memory and uploaded before the call returns (the upload
+ * runs beside the convolutions of the batches submitted before). */
 int ppg_submit_batch(ppg_ctx* ctx, const uint8_t* const* imgs, int n, int row_stride, int match_prev, float nnratio);
 int ppg_wait_batch(ppg_ctx* ctx, ppg_frame_out* outs, int32_t* matches12, int* n_matches);
 
@@ -152,6 +155,11 @@ int ppg_write_tensor(ppg_ctx* ctx, int which, int frame, const float* src, size_
  * D[i*nB + j] = || A[i] - B[j] ||_2, rows of `dim` floats.  Host pointers.  The sum runs over
  * d = 0..dim-1 as one fused-multiply-add chain per pair, then a correctly rounded square root. */
 int ppg_dist_matrix(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, int dim, float* D);
+
+/* DescriptorDistance for ONE pair on the host (feature/src/MapPoint.cpp:22-29; also called from MapPoint.cpp:277): the
+ * same chain as every kernel of the library, bit for bit, without a launch or a context — what the free function
+ * `float DescriptorDistance(const cv::Mat&, const cv::Mat&)` becomes. */
+float ppg_descriptor_distance(const float* a, const float* b, int dim);
 
 /* DescriptorDistance for listed pairs only: row i of A against the rows cand_idx[cand_off[i] .. cand_off[i+1]-1] of B,
  * D[k] for the k-th listed pair.  The inner arithmetic of every candidate-list matcher whose control flow stays on the

@@ -597,7 +597,20 @@ inline void se3_apply(const ppgo_pose* T, const float* p, float* o) {
 inline void cam_center(const ppgo_pose* T, float* ow) {  // Tcw.inverse().translation() = -R^T t
     for (int r = 0; r < 3; r++) ow[r] = -(T->R[r] * T->t[0] + T->R[3 + r] * T->t[1] + T->R[6 + r] * T->t[2]);
 }
+// mpCamera->project: Pinhole::project (sensors/src/Pinhole.cpp:32-38) or, for a fisheye rig, KannalaBrandt8::project
+// (sensors/src/KannalaBrandt8.cpp:43-59; the unqualified cos / sin of :57-58 are the double functions)
 inline void pinhole_project(const ppgo_cfg* c, const float* p, float* uv) {
+    if (c->fisheye) {
+        const float x2_plus_y2 = p[0] * p[0] + p[1] * p[1];
+        const float theta = atan2f(sqrtf(x2_plus_y2), p[2]);
+        const float psi = atan2f(p[1], p[0]);
+        const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+                    theta9 = theta7 * theta2;
+        const float r = theta + c->D[0] * theta3 + c->D[1] * theta5 + c->D[2] * theta7 + c->D[3] * theta9;
+        uv[0] = (float)((double)(c->K[0] * r) * std::cos((double)psi) + (double)c->K[2]);
+        uv[1] = (float)((double)(c->K[4] * r) * std::sin((double)psi) + (double)c->K[5]);
+        return;
+    }
     uv[0] = c->K[0] * p[0] / p[2] + c->K[2];
     uv[1] = c->K[4] * p[1] / p[2] + c->K[5];
 }

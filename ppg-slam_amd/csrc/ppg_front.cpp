@@ -65,7 +65,8 @@ struct DBuf {
 // line-graph tail
 // (ppg_submit_batch* / ppg_wait_batch).  The slot before the current one also is "the previous frame" of
 // every stream for frame-to-frame matching.
-constexpr int kSlots = 4;
+constexpr int kSlots = 5;      // one more than kMaxInflight: the slot handed out by a wait is not the next one to be reused
+constexpr int kMaxInflight = 4;
 constexpr int kLanes = 2;
 inline int next_slot(int s) { return (s + 1) % kSlots; }
 inline int prev_slot(int s) { return (s + kSlots - 1) % kSlots; }
@@ -296,6 +297,12 @@ void select_lane(ppg_ctx* c, int li) {
     c->feat = l.feat; c->pa_o = l.pa_o; c->da_o = l.da_o; c->hs0 = l.hs0; c->hs1 = l.hs1;
 }
 
+int inflight_count(const ppg_ctx* c) {
+    int k = 0;
+    for (const Slot& sl : c->slot) k += sl.inflight;
+    return k;
+}
+
 bool any_inflight(const ppg_ctx* c) {
     for (const Slot& sl : c->slot)
         if (sl.inflight) return true;
@@ -329,6 +336,11 @@ bool read_blob(const char* path, std::map<std::string, Tensor>& out, std::string
     for (size_t i = 0; ok && i < es.size(); i++) {
         const Entry& e = es[i];
         if (e.ndim > 4 || e.nbytes % 4 || e.nbytes > (1u << 28)) { ok = false; break; }
+        {   // the entry's shape must account for exactly its bytes
+            uint64_t prod = 1;
+            for (uint32_t k = 0; k < e.ndim; k++) prod *= e.dims[k];
+            if (prod * 4 != e.nbytes) { ok = false; break; }
+        }
         Tensor t;
         t.dims.assign(e.dims, e.dims + e.ndim);
         t.v.resize(e.nbytes / 4);
@@ -422,8 +434,10 @@ int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::str
         return fail(c, PPG_EIO, "weight blob lacks %s", name.c_str());
     const Tensor& w = wi->second;
     const int cout = w.dims[0], cin = w.dims[1], ks = w.dims[2];
+    if ((ks != 1 && ks != 3) || (int)w.dims[3] != ks || (int)bi->second.v.size() != cout)
+        return fail(c, PPG_EIO, "%s: unsupported shape", name.c_str());
     const int KC = ppg::conv_chunk(ks), NB = 32 * nt, taps = ks * ks, G = KC / 8;
-    if ((ks != 1 && ks != 3) || cin % KC) return fail(c, PPG_EIO, "%s: unsupported shape", name.c_str());
+    if (cin % KC) return fail(c, PPG_EIO, "%s: unsupported shape", name.c_str());
     const int nblk = (cout + NB - 1) / NB, nchunks = cin / KC;
     dc.ks = ks; dc.nt = nt; dc.cin = cin; dc.cout = cout; dc.nblk = nblk;
     auto orig = [&](int cp) -> int {
@@ -468,7 +482,9 @@ int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::str
                                 float wv = w.v[((size_t)o * cin + ci) * taps + tap];
                                 uint16_t hi, lo;
                                 if (c->cfg.precision == 3) {  // fp16 halves of the weight scaled by 2^10
-                                    wv = std::min(std::max(wv * 0x1p10f, -65504.f), 65504.f);  // |w| < 64 in these networks
+                                    if (!(std::fabs(wv) < 63.9f))
+                                        return fail(c, PPG_ERANGE, "%s: a weight of magnitude %g leaves the range of the fp16 split (< 63.9): use precision 0 or 1", name.c_str(), (double)wv);
+                                    wv = wv * 0x1p10f;
                                     hi = f16_rne(wv);
                                     lo = f16_rne(wv - f16_float(hi));
                                 } else {
@@ -495,6 +511,8 @@ int make_conv(ppg_ctx* c, const std::map<std::string, Tensor>& t, const std::str
              v = t.find(bn_name + ".running_var");
         if (g == t.end() || b == t.end() || m == t.end() || v == t.end())
             return fail(c, PPG_EIO, "weight blob lacks %s", bn_name.c_str());
+        if ((int)g->second.v.size() != cout || (int)b->second.v.size() != cout || (int)m->second.v.size() != cout || (int)v->second.v.size() != cout)
+            return fail(c, PPG_EIO, "%s: batch-norm vectors do not match %d output channels", bn_name.c_str(), cout);
         alpha.assign((size_t)nblk * NB, 1.f);
         beta.assign((size_t)nblk * NB, 0.f);
         for (int cp = 0; cp < nblk * NB; cp++) {
@@ -549,7 +567,7 @@ int load_weights(ppg_ctx* c) {
     auto w1 = t.find("backbone.conv1a.weight"), b1 = t.find("backbone.conv1a.bias");
     auto w3 = t.find("edge.conv_block_lst.3.weight"), b3 = t.find("edge.conv_block_lst.3.bias");
     if (w1 == t.end() || b1 == t.end() || w3 == t.end() || b3 == t.end() || w1->second.v.size() != 576 ||
-        w3->second.v.size() != 8)
+        w3->second.v.size() != 8 || b1->second.v.size() != 64 || b3->second.v.size() != 2)
         return fail(c, PPG_EIO, "weight blob lacks conv1a / final heat conv");
     std::vector<float> w1p(9 * 64);
     for (int o = 0; o < 64; o++)
@@ -964,8 +982,9 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     c->skip_score = c->skip_heat = c->skip_refine = false;
     {
         const int ns = next_slot(c->cur);
-        if (!c->slot[ns].inflight) select_lane(c, (c->lane_cur + 1) % c->nlanes);
-        if (c->slot[ns].inflight) return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
+        if (c->slot[ns].inflight || inflight_count(c) >= kMaxInflight)
+            return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
+        select_lane(c, (c->lane_cur + 1) % c->nlanes);
         select_slot(c, ns);
         c->slot[ns].n = n;
         c->slot[ns].matched = false;
@@ -1316,7 +1335,7 @@ static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int 
     if (!imgs || n < 1 || n > c->B || row_stride < c->W)
         return fail(c, PPG_EINVAL, "bad image batch (n = %d, max_batch = %d, row_stride = %d)", n, c->B, row_stride);
     Slot& nx = c->slot[next_slot(c->cur)];
-    if (nx.inflight) return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
+    if (nx.inflight || inflight_count(c) >= kMaxInflight) return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
     const size_t HW = (size_t)c->H * c->W;
     for (int b = 0; b < n; b++)
         if (!imgs[b]) return fail(c, PPG_EINVAL, "image %d is NULL", b);
@@ -1360,6 +1379,17 @@ int ppg_extract_batch_device(ppg_ctx* c, const uint8_t* d_imgs, int n, ppg_frame
 // ------------------------------------------------------------------------------------------
 // matching/
 // ------------------------------------------------------------------------------------------
+
+float ppg_descriptor_distance(const float* a, const float* b, int dim) {
+    // the chain every kernel of the library evaluates: one fused multiply-add per component, in order, then a
+    // correctly rounded square root — no launch, no context
+    float acc = 0.f;
+    for (int d = 0; d < dim; d++) {
+        const float t = a[d] - b[d];
+        acc = std::fmaf(t, t, acc);
+    }
+    return std::sqrt(acc);
+}
 
 int ppg_dist_matrix(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int dim, float* D) {
     if (!c) return PPG_EINVAL;
@@ -1543,6 +1573,8 @@ struct ppg_grid {
     int minX, minY, maxX, maxY;
     float invW, invH;
     int n;
+    int fisheye;   // camera model of the configuration the grid was built with (projection of ppg_check_in_frustum)
+    float D[4];
     std::vector<float> pos;
     std::vector<int32_t> cell[64][48];  // FRAME_GRID_COLS x FRAME_GRID_ROWS, sensors/include/GeometricCamera.h:79-80
 };
@@ -1584,6 +1616,8 @@ ppg_grid* ppg_grid_build(const ppg_config* cfg, const float* pos, int n) {
     } else {
         g->minX = 0; g->minY = 0; g->maxX = cfg->width; g->maxY = cfg->height;
     }
+    g->fisheye = cfg->fisheye;
+    for (int k = 0; k < 4; k++) g->D[k] = cfg->D[k];
     g->invW = 64.0f / (float)(g->maxX - g->minX);
     g->invH = 48.0f / (float)(g->maxY - g->minY);
     g->n = n;
@@ -1724,7 +1758,22 @@ int ppg_check_in_frustum(const ppg_grid* g, const float* K, const float* T, int 
         float Pc[3];
         for (int r = 0; r < 3; r++) Pc[r] = T[3 * r] * P[0] + T[3 * r + 1] * P[1] + T[3 * r + 2] * P[2] + T[9 + r];
         if (Pc[2] < 0.0f) continue;
-        const float u = K[0] * Pc[0] / Pc[2] + K[2], v = K[4] * Pc[1] / Pc[2] + K[5];  // Pinhole::project
+        float u, v;   // mpCamera->project (map/src/Frame.cpp:237)
+        if (g->fisheye) {
+            // KannalaBrandt8::project(const Eigen::Vector3f&) (sensors/src/KannalaBrandt8.cpp:43-59); the unqualified
+            // cos / sin of :57-58 are the double functions
+            const float x2_plus_y2 = Pc[0] * Pc[0] + Pc[1] * Pc[1];
+            const float theta = atan2f(sqrtf(x2_plus_y2), Pc[2]);
+            const float psi = atan2f(Pc[1], Pc[0]);
+            const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+                        theta9 = theta7 * theta2;
+            const float r = theta + g->D[0] * theta3 + g->D[1] * theta5 + g->D[2] * theta7 + g->D[3] * theta9;
+            u = (float)((double)(K[0] * r) * std::cos((double)psi) + (double)K[2]);
+            v = (float)((double)(K[4] * r) * std::sin((double)psi) + (double)K[5]);
+        } else {   // Pinhole::project (sensors/src/Pinhole.cpp:32-38)
+            u = K[0] * Pc[0] / Pc[2] + K[2];
+            v = K[4] * Pc[1] / Pc[2] + K[5];
+        }
         if (!ppg_grid_is_in_image(g, u, v)) continue;
         const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
         const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
@@ -1959,6 +2008,25 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
     if (n_matches) *n_matches = 0;
     const int m = g->m;
     if (m == 0 || n == 0) return PPG_OK;
+    {   // every id that is used as an index below
+        const int ne = g->edge_off[m];
+        if (g->edge_off[0] != 0 || ne < 0 || (ne && (!g->edge_other || !g->edge_ok || !g->edge_id)))
+            return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad edge lists");
+        for (int i = 0; i < m; i++)
+            if (g->edge_off[i + 1] < g->edge_off[i]) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_off must be non-decreasing");
+        for (int k = 0; k < ne; k++)
+            if (g->edge_other[k] < -1 || g->edge_other[k] >= m) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_other[%d] out of range", k);
+        for (int i = 0; i < n; i++)
+            if (frame_mp[i] < -1 || frame_mp[i] >= m) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: frame_mp[%d] out of range", i);
+        if (conn_off[0] != 0 || conn_off[n] < 0 || (conn_off[n] && (!conn_idx || !edge_idx)))
+            return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad key-edge lists");
+        for (int i = 0; i < n; i++)
+            if (conn_off[i + 1] < conn_off[i]) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: conn_off must be non-decreasing");
+        for (int k = 0; k < conn_off[n]; k++)
+            if ((int)conn_idx[k] >= n_edges) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: conn_idx[%d] out of range", k);
+        for (int e = 0; e < 2 * n_edges; e++)
+            if ((int)edge_idx[e] >= n) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_idx[%d] out of range", e);
+    }
     const float TH_HIGH = 0.8f;  // matching/src/Matcher.cpp:12
     // every DescriptorDistance the walk can ask for is an entry of the m x n matrix: one GPU pass
     std::vector<float> D((size_t)m * n);
@@ -1991,6 +2059,7 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
             else if (d < best2) best2 = d;
         }
         if (best > TH_HIGH && best > nnratio * best2) continue;  // :276
+        if (bestIdx < 0) continue;  // every candidate of the window was skipped (the reference indexes with -1 here, :279)
         frame_mp[bestIdx] = mp;
         tracked[mp] = 1;
         nmatches++;

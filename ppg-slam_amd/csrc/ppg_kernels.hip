@@ -924,7 +924,8 @@ __device__ inline void undistort_fisheye_dev(const NmsArgs& a, float x, float y,
     *ov = (float)(fy * (py * scale) + cy);
 }
 
-constexpr int EMIT_SORT_CAP = 8192;  // keys sorted in LDS (64 KiB); of larger sets only the best max_num are sorted
+constexpr int EMIT_SORT_CAP = 8192;  // keys the LDS sort buffer holds (64 KiB)
+constexpr int EMIT_SORT_ALL = 2048;  // up to this many kept pixels everything is sorted; of larger sets only the best max_num
 
 __device__ inline void emit_point(const NmsArgs& a, int b, const float* sc, uint32_t p, int rank) {
     const int x = (int)(p % (uint32_t)a.W), y = (int)(p / (uint32_t)a.W);
@@ -954,11 +955,12 @@ __global__ __launch_bounds__(1024) void nms_emit_kernel(NmsArgs a) {
     const uint32_t* kept = a.kept + (size_t)b * a.kept_cap;
     const int n = min(S, a.max_num);
     int m = S;  // keys to sort
-    if (S <= EMIT_SORT_CAP) {
+    if (S <= EMIT_SORT_ALL || S <= n) {
         for (int k = tid; k < S; k += 1024) skey[k] = prio_key(sc[kept[k]], kept[k]);
     } else {
-        // More kept pixels than fit the LDS sort: only the best n = max_num are emitted, so find the n-th largest
-        // key by radix select (8 bits per pass over the keys in memory; keys are distinct) and sort just those n.
+        // Many more kept pixels than are emitted: only the best n = max_num matter, so find the n-th largest key by
+        // radix select (8 bits per pass over the keys in memory; keys are distinct) and sort just those n — a
+        // 91-stage bitonic sort of 8192 keys costs far more than eight counting passes and a sort of n.
         unsigned long long* key = a.kept_key + (size_t)b * a.kept_cap;
         for (int k = tid; k < S; k += 1024) key[k] = prio_key(sc[kept[k]], kept[k]);
         __syncthreads();

@@ -405,8 +405,20 @@ private:
         Grid(const Grid&) = delete;
         Grid& operator=(const Grid&) = delete;
     };
-    // Pinhole::project (sensors/src/Pinhole.cpp:32-38)
+    // mpCamera->project: Pinhole::project (sensors/src/Pinhole.cpp:32-38) or KannalaBrandt8::project
+    // (sensors/src/KannalaBrandt8.cpp:43-59; its unqualified cos / sin are the double functions)
     void project(const float* p, float* uv) const {
+        if (mpCamera->mnType == CameraModel::CAM_FISHEYE) {
+            const float x2_plus_y2 = p[0] * p[0] + p[1] * p[1];
+            const float theta = atan2f(sqrtf(x2_plus_y2), p[2]);
+            const float psi = atan2f(p[1], p[0]);
+            const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+                        theta9 = theta7 * theta2;
+            const float r = theta + mpCamera->D[0] * theta3 + mpCamera->D[1] * theta5 + mpCamera->D[2] * theta7 + mpCamera->D[3] * theta9;
+            uv[0] = (float)((double)(mpCamera->K[0] * r) * std::cos((double)psi) + (double)mpCamera->K[2]);
+            uv[1] = (float)((double)(mpCamera->K[4] * r) * std::sin((double)psi) + (double)mpCamera->K[5]);
+            return;
+        }
         uv[0] = mpCamera->K[0] * p[0] / p[2] + mpCamera->K[2];
         uv[1] = mpCamera->K[4] * p[1] / p[2] + mpCamera->K[5];
     }

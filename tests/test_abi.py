@@ -84,13 +84,19 @@ def test_host_mirror_compiles():
     assert os.path.exists(demo)
 
 
-def test_check_in_frustum_host_logic_vs_oracle(pkg, orc):
-    """Frame::CheckInFrustum (map/src/Frame.cpp:223-260), batched: host arithmetic of the library against the oracle."""
+@pytest.mark.parametrize("fisheye", [0, 1])
+def test_check_in_frustum_host_logic_vs_oracle(fisheye, pkg, orc):
+    """Frame::CheckInFrustum (map/src/Frame.cpp:223-260), batched: host arithmetic of the library against the oracle,
+    with the pinhole projection and with KannalaBrandt8::project (sensors/src/KannalaBrandt8.cpp:43-59)."""
     W, H = 640, 480
     cfg = pkg.default_config(W, H)
     ocfg = orc.default_cfg(W, H)
     for k in range(9):
         ocfg.K[k] = cfg.K[k]
+    cfg.fisheye = ocfg.fisheye = fisheye
+    if fisheye:
+        for k, v in enumerate((-0.01, 0.004, -0.002, 0.0005)):
+            cfg.D[k] = ocfg.D[k] = v
     rng = np.random.default_rng(11)
     m = 400
     pos = np.stack([rng.uniform(-3, 3, m), rng.uniform(-2, 2, m), rng.uniform(-1, 6, m)], 1).astype(np.float32)
@@ -123,3 +129,19 @@ def test_check_in_frustum_host_logic_vs_oracle(pkg, orc):
     assert np.array_equal(in_view, o_in) and np.array_equal(proj, o_proj) and np.array_equal(depth, o_depth)
     assert np.array_equal(vc, o_vc, equal_nan=True)
     assert np.all(proj[in_view == 0] == -1) and np.all(depth[in_view == 0] == -1)
+
+
+def test_descriptor_distance_host_chain(pkg, orc):
+    """ppg_descriptor_distance (no launch, no context) is the oracle's DescriptorDistance bit for bit."""
+    L = pkg.lib()
+    L.ppg_descriptor_distance.restype = C.c_float
+    rng = np.random.default_rng(21)
+    for _ in range(200):
+        a = rng.normal(size=256).astype(np.float32)
+        b = (a + rng.normal(size=256).astype(np.float32) * np.float32(rng.uniform(0, 2))).astype(np.float32)
+        a /= np.linalg.norm(a)
+        b /= np.linalg.norm(b)
+        got = L.ppg_descriptor_distance(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 256)
+        assert np.float32(got) == np.float32(orc.descriptor_distance(a, b))
+    z = np.zeros(256, np.float32)
+    assert L.ppg_descriptor_distance(z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), 256) == 0.0

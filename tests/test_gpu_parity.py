@@ -824,3 +824,23 @@ def test_fused_match_equals_matrix_path(pkg, orc, synth, monkeypatch):
                 assert cnts_f[b] == co and np.array_equal(m_f[b, :f0["n"]], mo), (kind, t, b)
             assert cnts_f[:3].min() > 50
         ref.close()
+
+
+def test_waited_results_survive_the_next_submit(pkg, synth):
+    """Four batches in flight, the bench's pattern: the buffers behind the frames that ppg_wait_batch hands out must
+    still hold that batch after ONE more submit (the ring has one slot more than may be in flight)."""
+    H, W = 96, 128
+    ctx = get_ctx(pkg, W, H, 500, batch=4)
+    seqs = [[synth.make_frame(H, W, 300 + 7 * t + s, t, "dense" if (s + t) % 2 else "sparse") for s in range(3)] for t in range(7)]
+    ref = [ctx.extract_batch(seqs[t]) for t in range(7)]
+    for t in range(4):
+        ctx.submit_batch(seqs[t], match_prev=t > 0)
+    for t in range(3):
+        outs, _, _, n = ctx.wait_batch(to_dict=False)      # raw pointers into the slot of batch t
+        ctx.submit_batch(seqs[4 + t], match_prev=True)      # the next submit must not touch them
+        frames = [pkg._frame_to_dict(outs[i]) for i in range(n)]
+        for r, s in zip(frames, ref[t]):
+            for k in ("xy", "score", "un", "desc", "edge_idx", "edge_score", "conn_idx", "coline_pairs"):
+                assert np.array_equal(r[k], s[k], equal_nan=True), (t, k)
+    for t in range(4):
+        ctx.wait_batch()

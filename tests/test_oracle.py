@@ -368,3 +368,38 @@ def test_reduced_precision_statements_against_the_reference_nets(onet):
         worst = max(float(np.abs(t[k] - g[k]).max() / np.abs(g[k]).max()) for k in ("feat", "junc", "desc"))
         assert worst <= tol, (prec, worst)
         assert worst >= floor.get(prec, 0.0), (prec, worst)
+
+
+def test_line_graph_sensitivity_to_libm_reading(orc, onet, synth, capsys):
+    """detectLines calls atan2, abs and sin without saying which overload (feature/src/PPGExtractor.cpp:283, :325, :330,
+    :413).  The oracle can read them three ways (ppgo_cfg.math_mode); this measures, on the golden images and two full-size
+    synthetic frames, whether any edge decision depends on the choice between the float libm functions (mode 0) and the
+    double functions rounded to float (mode 1, the statement the GPU tail implements): none may.  Mode 2 (integer abs, a
+    different algorithm) is reported only."""
+    from conftest import golden
+    cases = []
+    for name in ("cnn_96x128_s1_sparse.npz", "cnn_128x160_s7_dense.npz", "cnn_64x96_s3_sparse.npz"):
+        g = golden(name)
+        H, W = g["img"].shape
+        cases.append((name, W, H, 500, g["refined"], g["kp_un"], g["kp_out"]))
+    for (seed, kind, maxn) in ((11, "dense", 1024), (1, "sparse", 500)):
+        H, W = 480, 640
+        cfg = orc.default_cfg(W, H, maxn)
+        t = onet.inference(synth.make_frame(H, W, seed, 0, kind))
+        kp = orc.detect_keypoints(cfg, orc.score_map(t["junc"]))
+        cases.append((f"{kind}{seed}", W, H, maxn, orc.refine_heat(cfg, orc.heat_prob(t["heat"])), kp["un"], kp["out"]))
+    report = []
+    for name, W, H, maxn, refined, un, out in cases:
+        res = []
+        for mode in (0, 1, 2):
+            cfg = orc.default_cfg(W, H, maxn)
+            cfg.math_mode = mode
+            res.append(orc.detect_lines(cfg, refined, un, out))
+        for k in ("edge_idx", "conn_off", "conn_idx", "coline_off", "coline_pairs"):
+            assert np.array_equal(res[0][k], res[1][k]), (name, k)
+        assert np.array_equal(res[0]["edge_score"], res[1]["edge_score"], equal_nan=True)
+        a = {tuple(e) for e in res[1]["edge_idx"].tolist()}
+        b = {tuple(e) for e in res[2]["edge_idx"].tolist()}
+        report.append(f"{name}: {len(a)} edges, float-vs-double libm reading: identical; integer abs changes {len(a ^ b)} edges")
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
