@@ -193,7 +193,8 @@ def main():
         for t in range(T):
             host[t, s] = synth.frame_from_scene(scene, H, W, t)
     frames = torch.from_numpy(host).cuda()
-    shutter = importlib.import_module("ppg_slam_amd.streams").ShutterBarrier(dist, "cuda")
+    streams_mod = importlib.import_module("ppg_slam_amd.streams")
+    shutter = streams_mod.ShutterBarrier(dist, "cuda")
 
     def barrier():
         torch.cuda.synchronize()
@@ -215,23 +216,16 @@ def main():
 
     def wait(k):
         outs, cnts, _, n = ctx.wait_batch(to_dict=False, want_matches=True)
-        shutter.release(k)  # global-shutter barrier: frame group k is released on every GPU together
         stats["kp"] += sum(outs[b].n for b in range(n))
         stats["edges"] += sum(outs[b].n_edges for b in range(n))
         stats["matches"] += int(cnts.sum())
 
     def run(first, count):
-        """`count` steps, software-pipelined four deep: the CNNs of batches k+3 and k+2 (two lanes), the
-        post-processing of k+1 and the host's line-graph tail of k overlap."""
-        depth, done = 4, first
-        for k in range(first, first + count):
-            submit(k)
-            if k - done + 1 >= depth:
-                wait(done)
-                done += 1
-        while done < first + count:
-            wait(done)
-            done += 1
+        """`count` steps, software-pipelined four deep (the CNN of batches k+3 and k+2, the post-processing of k+1 and
+        the collection of k overlap); every collected group passes the global-shutter barrier (non-blocking all-reduce),
+        and the barriers still in flight are waited for before the step count is complete."""
+        streams_mod.run_steps(submit, wait, shutter, first, count, depth=4)
+        shutter.drain()
 
     # The first second of sustained load runs 5-10 % slower than the steady state (clock and power ramp of an
     # idle GPU, first-touch of the pinned result rings): an untimed pre-roll makes sure that at least PREROLL

@@ -807,7 +807,12 @@ static int create_impl(ppg_ctx* c) {
         const char* lh = getenv("PPG_LINES_HOST");
         c->lines_on_host = (lh && atoi(lh) != 0) || c->dump_tail;
         const char* e = getenv("PPG_HOST_THREADS");
-        int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        // Default: the host's hardware threads divided by the ranks sharing it (torchrun exports LOCAL_WORLD_SIZE), at
+        // most 8 — the pool only stages image batches into pinned memory and redoes the rare line-graph tails the
+        // device hands over, so eight ranks must not start 8 x 16 threads.
+        const char* lw = getenv("LOCAL_WORLD_SIZE");
+        const int ranks = std::max(1, lw ? atoi(lw) : 1);
+        int t = e ? atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / (unsigned)ranks));
         c->host_threads = std::max(1, std::min(t, 64));
     }
     int rc = load_weights(c);

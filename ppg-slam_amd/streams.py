@@ -23,18 +23,83 @@ def shard_streams(n_streams: int, world: int, rank: int):
 
 
 class ShutterBarrier:
-    """all-reduce(MIN) of the per-rank frame-group counter; returns the group every rank has finished."""
+    """all-reduce(MIN) of the per-rank frame-group counter: group k is released once every rank has finished it.
 
-    def __init__(self, dist, device):
+    release() never blocks on the collective: it starts the all-reduce of this rank's newest finished group (on the
+    GPU the result is copied to pinned memory behind it and an event marks its arrival) and returns the newest group
+    known to be released everywhere, which may lag by the collectives still in flight.  drain() waits for those.
+    Every rank must call release() the same number of times (it is a collective); `count` tells how many were started."""
+
+    def __init__(self, dist, device, depth=8):
         self.dist = dist
-        self.seq = torch.zeros(1, dtype=torch.int32, device=device)
+        self.active = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        self.cuda = str(device).startswith("cuda")
+        self.depth = depth
+        self.count = 0
+        self.released = -1
+        self.pending = []   # (tensor or pinned copy, handle): oldest first
+        if self.active:
+            self.dev = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(depth)]
+            self.host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(depth)] if self.cuda else None
+
+    def _done(self, entry):
+        buf, handle = entry
+        return handle.query() if self.cuda else handle.is_completed()
+
+    def _retire(self, block):
+        while self.pending and (block or self._done(self.pending[0])):
+            buf, handle = self.pending.pop(0)
+            if self.cuda:
+                handle.synchronize()
+            else:
+                handle.wait()
+            self.released = max(self.released, int(buf[0]))
+            block = False
 
     def release(self, group: int) -> int:
-        if self.dist is None or not self.dist.is_initialized() or self.dist.get_world_size() == 1:
+        self.count += 1
+        if not self.active:
+            self.released = group
             return group
-        self.seq.fill_(group)
-        self.dist.all_reduce(self.seq, op=self.dist.ReduceOp.MIN)
-        return int(self.seq.item())
+        if len(self.pending) >= self.depth:
+            self._retire(block=True)       # the ring is full: wait for the oldest collective only
+        slot = (self.count - 1) % self.depth
+        t = self.dev[slot]
+        t.fill_(group)
+        if self.cuda:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)   # enqueued; the host does not wait
+            self.host[slot].copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending.append((self.host[slot], ev))
+        else:
+            work = self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, async_op=True)
+            self.pending.append((t, work))
+        self._retire(block=False)
+        return self.released
+
+    def drain(self) -> int:
+        while self.pending:
+            self._retire(block=True)
+        return self.released
+
+
+def run_steps(submit, wait, shutter, first, count, depth=4):
+    """`count` steps of a software pipeline `depth` deep: submit(k) enqueues frame group k, wait(k) collects it, and every
+    collected group goes through the global-shutter barrier.  Returns the number of groups collected.  The loop of
+    bench.py, kept here so that the multi-rank test drives the same code."""
+    done = first
+    for k in range(first, first + count):
+        submit(k)
+        if k - done + 1 >= depth:
+            wait(done)
+            shutter.release(done)
+            done += 1
+    while done < first + count:
+        wait(done)
+        shutter.release(done)
+        done += 1
+    return done - first
 
 
 class StereoExchange:

@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
     released = []
     for k in range(5):
         done = k if rank == 0 else max(0, k - 1)  # rank 1 lags one frame group behind
-        released.append(bar.release(done))
+        bar.release(done)
+        released.append(bar.drain())              # release() itself does not wait for the collective
     # every rank sees the same release sequence = the slowest rank's progress
     gathered = [None] * world
     dist.all_gather_object(gathered, (mine, released))
@@ -103,3 +104,50 @@ def test_shard_streams_covers_everything():
         assert got == list(range(19))
     with pytest.raises(ValueError):
         streams.shard_streams(4, 2, 2)
+
+
+def _loop_worker(rank, world, port, q):
+    """bench.py's step loop (streams.run_steps) with a stub in place of the GPU context: rank 1 is slower."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    load_pkg()
+    streams = importlib.import_module("ppg_slam_amd.streams")
+    bar = streams.ShutterBarrier(dist, "cpu", depth=3)
+    log, seen = [], []
+
+    def submit(k):
+        log.append(("s", k))
+
+    def wait(k):
+        time.sleep(0.002 * (1 + 2 * rank))
+        log.append(("w", k))
+        seen.append(bar.released)   # what was known to be released before this group's barrier started
+
+    total = 0
+    for first, count in ((0, 9), (9, 1), (10, 6)):
+        total += streams.run_steps(submit, wait, bar, first, count, depth=4)
+        assert bar.drain() == first + count - 1        # every rank has finished every group of the pass
+    q.put((rank, total, bar.count, log, seen))
+    dist.destroy_process_group()
+
+
+def test_step_loop_barrier_counts_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_loop_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, total, count, log, seen in res:
+        assert total == 16 and count == 16                      # one barrier per collected group on every rank
+        assert [k for t, k in log if t == "s"] == list(range(16)) and [k for t, k in log if t == "w"] == list(range(16))
+        # at most four groups are in flight: group k is collected before group k + 4 is submitted
+        pos = {e: i for i, e in enumerate(log)}
+        assert all(pos[("w", k)] < pos[("s", k + 4)] for k in range(12) if k + 4 < 9 or k >= 10)
+        assert seen == sorted(seen) and all(v < k for k, v in enumerate(seen))   # never ahead of the slowest rank
