@@ -339,6 +339,36 @@ int ppg_profile_read(ppg_ctx* ctx, double* ms, long long* launches);
 /* Algorithmic FLOPs (2 x MACs of the layers' shapes) enqueued per class since ppg_profile(ctx, 1); conv classes only. */
 int ppg_profile_flops(ppg_ctx* ctx, double* flops);
 
+/* ---- DBoW3 vocabulary (map/src/Frame.cpp:131, :338: pMap->mpVoc->transform(vCurrentDesc, mBowVec, mFeatVec, 4)) ----
+ * DBoW3 is a third-party dependency of the reference that is not vendored; its binary vocabulary format and its tree
+ * descent are restated from DBoW3's published source. */
+typedef struct ppg_vocab ppg_vocab;
+/* DBoW3::Vocabulary::load of a binary vocabulary (Vocabulary/voc_euroc_9x3.gz and voc_tum_9x3.gz are such files despite
+ * the suffix; QuickLZ level-1 packets are decoded).  Host only.  NULL on failure, reason in ppg_last_error(NULL). */
+ppg_vocab* ppg_vocab_load(const char* path);
+void ppg_vocab_free(ppg_vocab* v);
+/* k, L, node count (root included), word count, descriptor length, DBoW3::ScoringType, DBoW3::WeightingType; any pointer may be NULL */
+int ppg_vocab_info(const ppg_vocab* v, int* k, int* L, int* n_nodes, int* n_words, int* dim, int* scoring, int* weighting);
+/* one node of the tree: parent (-1 for the root), weight, word id (-1 for inner nodes), children in visiting order, descriptor */
+int ppg_vocab_node(const ppg_vocab* v, int node, int* parent, double* weight, int* word_id, int* n_children,
+                   const int32_t** children, const float** desc);
+/* Vocabulary::transform(feature, word_id, weight, nid, levelsup) for n descriptors (host pointers, rows of the
+ * vocabulary's descriptor length) in one launch: the leaf's word id and weight and the id of the node passed at level
+ * L - levelsup (0, the root, when that is <= 0 — the reference's levelsup = 4 with its L = 3 vocabularies). */
+int ppg_bow_transform(ppg_ctx* ctx, const ppg_vocab* v, const float* desc, int n, int levelsup,
+                      int32_t* word_id, double* weight, int32_t* node_id);
+/* The same for the first n_frames frames of the last ppg_extract* call, whose descriptors are still on the GPU: outputs
+ * hold n_frames rows of junction_max_num entries (-1 / 0 beyond a frame's key points). */
+int ppg_bow_transform_batch(ppg_ctx* ctx, const ppg_vocab* v, int n_frames, int levelsup,
+                            int32_t* word_id, double* weight, int32_t* node_id);
+/* The two containers transform() fills, from the per-feature results (host): BowVector as (word id, value) ascending by
+ * word — weights added per word (TF_IDF, TF) or first kept (IDF, BINARY), then normalised as the vocabulary's scoring
+ * type demands — and FeatureVector as CSR: node ids ascending, the feature indices of each in feature order.  Features
+ * whose word weight is 0 enter neither.  Capacities: n entries each (fv_off n + 1). */
+int ppg_bow_vectors(const ppg_vocab* v, const int32_t* word_id, const double* weight, const int32_t* node_id, int n,
+                    int32_t* bow_word, double* bow_value, int* n_bow,
+                    int32_t* fv_node, int32_t* fv_off, int32_t* fv_idx, int* n_fv);
+
 /* Where the order-dependent tail of detectLines (feature/src/PPGExtractor.cpp:315-441) ran since ppg_create: *frames =
  * frames collected, *host_frames = those whose tail the host statement had to redo (the device tail hands a frame over
  * when a double-precision atan2 / sin result sits within 64 ulps of a float rounding boundary, where another libm could

@@ -422,3 +422,20 @@ def extract(net, cfg, img):
     res.update(detect_lines(cfg, refined, kp["un"], kp["out"]))
     res["desc"] = gen_descriptors(cfg, t["desc"], kp["xy"])
     return res
+
+
+def bow_transform(voc, desc, levelsup):
+    """Vocabulary::transform per descriptor on a vocabulary dict of oracle/vocab.py: (word ids, weights, node ids)."""
+    desc = np.ascontiguousarray(desc, np.float32)
+    n = desc.shape[0]
+    nd = np.ascontiguousarray(voc["desc"], np.float32)
+    co = np.ascontiguousarray(voc["child_off"], np.int32)
+    ci = np.ascontiguousarray(voc["child_idx"], np.int32)
+    wi = np.ascontiguousarray(voc["word_id"], np.int32)
+    wt = np.ascontiguousarray(voc["weight"], np.float64)
+    ow = np.zeros(n, np.int32)
+    owt = np.zeros(n, np.float64)
+    on = np.zeros(n, np.int32)
+    lib().ppgo_bow_transform(_p(desc), n, int(voc["dim"]), _p(nd), _p(co), _p(ci), _p(wi), _p(wt), int(voc["L"]), int(levelsup),
+                             _p(ow), _p(owt), _p(on))
+    return ow, owt, on

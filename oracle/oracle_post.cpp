@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -1060,6 +1061,32 @@ int ppgo_extend_map_matches(const ppgo_cfg* c, float nnratio, float th, const pp
     }
     ppgo_grid_free(grid);
     return nmatches;
+}
+
+void ppgo_bow_transform(const float* desc, int n, int dim, const float* node_desc, const int32_t* child_off,
+                        const int32_t* child_idx, const int32_t* word_id, const double* weight, int L, int levelsup,
+                        int32_t* out_word, double* out_weight, int32_t* out_node) {
+    const int nid_level = L - levelsup;
+    for (int f = 0; f < n; f++) {
+        const float* x = desc + (size_t)f * dim;
+        int final_id = 0, current_level = 0, nid = 0;   // nid_level <= 0: the root
+        do {
+            ++current_level;
+            double best_d = std::numeric_limits<double>::max();
+            const int start = final_id;
+            for (int k = child_off[start]; k < child_off[start + 1]; k++) {
+                const int id = child_idx[k];
+                const float* y = node_desc + (size_t)id * dim;
+                double sqd = 0.;
+                for (int i = 0; i < dim; i++) sqd += (x[i] - y[i]) * (x[i] - y[i]);
+                if (sqd < best_d) { best_d = sqd; final_id = id; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (child_off[final_id + 1] != child_off[final_id]);
+        out_word[f] = word_id[final_id];
+        out_weight[f] = weight[final_id];
+        out_node[f] = nid;
+    }
 }
 
 }  // extern "C"

@@ -387,3 +387,72 @@ class Context:
                                                 _p(pos_un), desc.shape[0], _p(edge_idx), edge_idx.shape[0], _p(conn_off),
                                                 _p(conn_idx), _p(tracked), _p(frame_mp), _p(frame_me), C.byref(cnt)))
         return cnt.value, tracked, frame_mp, frame_me
+
+
+class Vocabulary:
+    """ppg_vocab: a DBoW3 binary vocabulary loaded by the library (host)."""
+
+    def __init__(self, path):
+        self.L_ = lib()
+        self.L_.ppg_vocab_load.restype = C.c_void_p
+        self.L_.ppg_vocab_load.argtypes = [C.c_char_p]
+        self.L_.ppg_vocab_free.argtypes = [C.c_void_p]
+        self.h = self.L_.ppg_vocab_load(os.path.abspath(path).encode())
+        if not self.h:
+            raise PPGError("ppg_vocab_load failed: " + self.L_.ppg_last_error(None).decode())
+        v = [C.c_int(0) for _ in range(7)]
+        self.L_.ppg_vocab_info(C.c_void_p(self.h), *[C.byref(x) for x in v])
+        self.k, self.L, self.n_nodes, self.n_words, self.dim, self.scoring, self.weighting = [x.value for x in v]
+
+    def node(self, i):
+        par, w, wid, nc = C.c_int(0), C.c_double(0), C.c_int(0), C.c_int(0)
+        ch, d = C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
+        rc = self.L_.ppg_vocab_node(C.c_void_p(self.h), i, C.byref(par), C.byref(w), C.byref(wid), C.byref(nc), C.byref(ch), C.byref(d))
+        if rc:
+            raise PPGError("ppg_vocab_node failed")
+        return (par.value, w.value, wid.value, [ch[k] for k in range(nc.value)],
+                np.ctypeslib.as_array(d, (self.dim,)).copy())
+
+    def bow_vectors(self, word_id, weight, node_id):
+        n = len(word_id)
+        word_id = np.ascontiguousarray(word_id, np.int32)
+        weight = np.ascontiguousarray(weight, np.float64)
+        node_id = np.ascontiguousarray(node_id, np.int32)
+        bw, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        fn, fo, fi = np.zeros(max(n, 1), np.int32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.int32)
+        nb, nf = C.c_int(0), C.c_int(0)
+        rc = self.L_.ppg_bow_vectors(C.c_void_p(self.h), _p(word_id), _p(weight), _p(node_id), n, _p(bw), _p(bv), C.byref(nb),
+                                     _p(fn), _p(fo), _p(fi), C.byref(nf))
+        if rc:
+            raise PPGError("ppg_bow_vectors failed")
+        bow = [(int(bw[k]), float(bv[k])) for k in range(nb.value)]
+        fv = [(int(fn[q]), [int(x) for x in fi[fo[q]:fo[q + 1]]]) for q in range(nf.value)]
+        return bow, fv
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L_.ppg_vocab_free(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bow_transform(ctx, voc, desc, levelsup=4):
+    """ppg_bow_transform for host descriptors."""
+    desc = np.ascontiguousarray(desc, np.float32)
+    n = desc.shape[0]
+    w, wt, nd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64), np.zeros(max(n, 1), np.int32)
+    ctx._chk(ctx.L.ppg_bow_transform(C.c_void_p(ctx.h), C.c_void_p(voc.h), _p(desc), n, levelsup, _p(w), _p(wt), _p(nd)))
+    return w[:n], wt[:n], nd[:n]
+
+
+def bow_transform_batch(ctx, voc, n_frames, levelsup=4):
+    """ppg_bow_transform_batch: the resident descriptors of the last extracted batch."""
+    M = int(ctx.cfg.junction_max_num)
+    w, wt, nd = np.zeros((n_frames, M), np.int32), np.zeros((n_frames, M), np.float64), np.zeros((n_frames, M), np.int32)
+    ctx._chk(ctx.L.ppg_bow_transform_batch(C.c_void_p(ctx.h), C.c_void_p(voc.h), n_frames, levelsup, _p(w), _p(wt), _p(nd)))
+    return w, wt, nd

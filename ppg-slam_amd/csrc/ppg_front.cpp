@@ -7,6 +7,7 @@
 #include "ppg_kernels.h"
 #include "host_pool.h"
 #include "lines_tail.h"
+#include "vocab.h"
 
 #include <algorithm>
 #include <chrono>
@@ -198,6 +199,13 @@ struct ppg_ctx {
     DBuf<int32_t> mListCnt, mNearLen;
     DBuf<float> mListRad;
     DBuf<uint16_t> mListCol;
+    // device copy of the vocabulary last used with ppg_bow_transform*
+    unsigned long long voc_serial = 0;
+    float* voc_desc = nullptr;
+    int *voc_child_off = nullptr, *voc_child_idx = nullptr, *voc_word = nullptr;
+    double* voc_weight = nullptr;
+    DBuf<int32_t> bWord, bNode;
+    DBuf<double> bWeight;
     bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
     int* mCount = nullptr;
     int* h_mcount = nullptr;
@@ -744,7 +752,8 @@ void ppg_destroy(ppg_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
-                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mNearLen.p, c->mListRad.p};
+                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p,
+                  c->voc_desc, c->voc_child_off, c->voc_child_idx, c->voc_word, c->voc_weight};
     for (void* p : ms)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_all) (void)hipEventDestroy(e);
@@ -2111,6 +2120,171 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
     }
     ppg_grid_free(grid);
     if (n_matches) *n_matches = nmatches;
+    return PPG_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// DBoW3 vocabulary: loader, tree descent on the GPU, BowVector / FeatureVector assembly
+// ------------------------------------------------------------------------------------------
+namespace {
+std::atomic<unsigned long long> g_vocab_serial{1};
+
+int vocab_to_device(ppg_ctx* c, const ppg_vocab* v) {
+    if (c->voc_serial == v->serial) return PPG_OK;
+    void* old[] = {c->voc_desc, c->voc_child_off, c->voc_child_idx, c->voc_word, c->voc_weight};
+    for (void* p : old)
+        if (p) HIPCHK(c, hipFree(p));
+    c->voc_desc = nullptr; c->voc_child_off = c->voc_child_idx = c->voc_word = nullptr; c->voc_weight = nullptr;
+    c->voc_serial = 0;
+    auto up = [&](auto** dst, const auto& vec) -> int {
+        void* q = nullptr;
+        HIPCHK(c, hipMalloc(&q, std::max<size_t>(vec.size(), 1) * sizeof(vec[0])));
+        *dst = (std::remove_reference_t<decltype(**dst)>*)q;
+        if (!vec.empty()) HIPCHK(c, hipMemcpy(q, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
+        return PPG_OK;
+    };
+    int rc = up(&c->voc_desc, v->desc);
+    if (!rc) rc = up(&c->voc_child_off, v->child_off);
+    if (!rc) rc = up(&c->voc_child_idx, v->child_idx);
+    if (!rc) rc = up(&c->voc_word, v->word_id);
+    if (!rc) rc = up(&c->voc_weight, v->weight);
+    if (rc) return rc;
+    c->voc_serial = v->serial;
+    return PPG_OK;
+}
+
+int bow_run(ppg_ctx* c, const ppg_vocab* v, const float* d_desc, size_t stride_batch, int n, const int* n_dev, int sn, int batch,
+            int levelsup, int32_t* word_id, double* weight, int32_t* node_id) {
+    int rc = vocab_to_device(c, v);
+    if (!rc) rc = grow(c, c->bWord, (size_t)n * batch);
+    if (!rc) rc = grow(c, c->bNode, (size_t)n * batch);
+    if (!rc) rc = grow(c, c->bWeight, (size_t)n * batch);
+    if (rc) return rc;
+    hipStream_t s = c->post;
+    ppg::BowArgs a;
+    a.desc = d_desc; a.stride_batch = stride_batch; a.n = n; a.n_dev = n_dev; a.sn = sn;
+    a.node_desc = c->voc_desc; a.child_off = c->voc_child_off; a.child_idx = c->voc_child_idx; a.word_id = c->voc_word;
+    a.weight = c->voc_weight; a.dim = v->dim; a.nid_level = v->L - levelsup;
+    a.out_word = c->bWord.p; a.out_weight = c->bWeight.p; a.out_node = c->bNode.p;
+    HIPCHK(c, ppg::launch_bow_transform(a, batch, s));
+    HIPCHK(c, hipMemcpyAsync(word_id, c->bWord.p, sizeof(int32_t) * (size_t)n * batch, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(weight, c->bWeight.p, sizeof(double) * (size_t)n * batch, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(node_id, c->bNode.p, sizeof(int32_t) * (size_t)n * batch, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return PPG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+ppg_vocab* ppg_vocab_load(const char* path) {
+    if (!path) { fail(nullptr, PPG_EINVAL, "ppg_vocab_load: path is NULL"); return nullptr; }
+    std::string why;
+    ppg_vocab* v = vocab_parse(path, why);
+    if (!v) { fail(nullptr, PPG_EIO, "%s", why.c_str()); return nullptr; }
+    v->serial = g_vocab_serial.fetch_add(1);
+    return v;
+}
+
+void ppg_vocab_free(ppg_vocab* v) { delete v; }
+
+int ppg_vocab_info(const ppg_vocab* v, int* k, int* L, int* n_nodes, int* n_words, int* dim, int* scoring, int* weighting) {
+    if (!v) return PPG_EINVAL;
+    if (k) *k = v->k;
+    if (L) *L = v->L;
+    if (n_nodes) *n_nodes = v->n_nodes;
+    if (n_words) *n_words = v->n_words;
+    if (dim) *dim = v->dim;
+    if (scoring) *scoring = v->scoring;
+    if (weighting) *weighting = v->weighting;
+    return PPG_OK;
+}
+
+int ppg_vocab_node(const ppg_vocab* v, int node, int* parent, double* weight, int* word_id, int* n_children,
+                   const int32_t** children, const float** desc) {
+    if (!v || node < 0 || node >= v->n_nodes) return PPG_EINVAL;
+    if (parent) *parent = v->parent[node];
+    if (weight) *weight = v->weight[node];
+    if (word_id) *word_id = v->word_id[node];
+    if (n_children) *n_children = v->child_off[node + 1] - v->child_off[node];
+    if (children) *children = v->child_idx.data() + v->child_off[node];
+    if (desc) *desc = v->desc.data() + (size_t)node * v->dim;
+    return PPG_OK;
+}
+
+int ppg_bow_transform(ppg_ctx* c, const ppg_vocab* v, const float* desc, int n, int levelsup, int32_t* word_id, double* weight,
+                      int32_t* node_id) {
+    if (!c) return PPG_EINVAL;
+    if (!v || n < 0 || (n && (!desc || !word_id || !weight || !node_id)))
+        return fail(c, PPG_EINVAL, "ppg_bow_transform: bad argument");
+    if (n == 0) return PPG_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    int rc = grow(c, c->mA, (size_t)n * v->dim);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->mA.p, desc, sizeof(float) * (size_t)n * v->dim, hipMemcpyHostToDevice, c->post));
+    return bow_run(c, v, c->mA.p, 0, n, nullptr, 0, 1, levelsup, word_id, weight, node_id);
+}
+
+int ppg_bow_transform_batch(ppg_ctx* c, const ppg_vocab* v, int n_frames, int levelsup, int32_t* word_id, double* weight,
+                            int32_t* node_id) {
+    if (!c) return PPG_EINVAL;
+    const Slot& sl = c->slot[c->cur];
+    if (any_inflight(c)) return fail(c, PPG_EINVAL, "a submitted batch is pending");
+    if (!v || v->dim != 256 || n_frames < 1 || n_frames > sl.n || !word_id || !weight || !node_id)
+        return fail(c, PPG_EINVAL, "ppg_bow_transform_batch: needs a 256-component vocabulary and frames of the last extracted batch");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int M = c->maxn;
+    int rc = bow_run(c, v, c->desc, (size_t)M * 256, M, c->counters + 3, 8, n_frames, levelsup, word_id, weight, node_id);
+    if (rc) return rc;
+    for (int b = 0; b < n_frames; b++)   // rows beyond a frame's key points
+        for (int i = sl.nkp[b]; i < M; i++) {
+            word_id[(size_t)b * M + i] = -1; weight[(size_t)b * M + i] = 0.0; node_id[(size_t)b * M + i] = -1;
+        }
+    return PPG_OK;
+}
+
+int ppg_bow_vectors(const ppg_vocab* v, const int32_t* word_id, const double* weight, const int32_t* node_id, int n,
+                    int32_t* bow_word, double* bow_value, int* n_bow, int32_t* fv_node, int32_t* fv_off, int32_t* fv_idx, int* n_fv) {
+    if (!v || n < 0 || !n_bow || !n_fv || !fv_off || (n && (!word_id || !weight || !node_id || !bow_word || !bow_value || !fv_node || !fv_idx)))
+        return PPG_EINVAL;
+    // Vocabulary::transform(features, BowVector&, FeatureVector&, levelsup): both containers are std::map, i.e. ordered
+    // by key; a feature whose word has weight 0 enters neither
+    std::map<int32_t, double> bow;
+    std::map<int32_t, std::vector<int32_t>> fv;
+    const bool tf = v->weighting == 0 || v->weighting == 1;   // TF_IDF, TF: weights add up; IDF, BINARY: first one stays
+    for (int i = 0; i < n; i++) {
+        if (word_id[i] < 0 || !(weight[i] > 0)) continue;
+        auto it = bow.find(word_id[i]);
+        if (it == bow.end()) bow[word_id[i]] = weight[i];
+        else if (tf) it->second += weight[i];
+        fv[node_id[i]].push_back(i);
+    }
+    // ScoringObject::mustNormalize: L1_NORM, CHI_SQUARE, KL, BHATTACHARYYA -> L1; L2_NORM -> L2; DOT_PRODUCT -> none
+    const int norm = v->scoring == 1 ? 2 : (v->scoring == 5 ? 0 : 1);
+    if (tf && norm == 0 && !bow.empty()) {
+        const double nd = (double)bow.size();
+        for (auto& kv : bow) kv.second /= nd;
+    }
+    if (norm != 0) {   // BowVector::normalize
+        double s = 0.0;
+        for (auto& kv : bow) s += norm == 1 ? std::fabs(kv.second) : kv.second * kv.second;
+        if (norm == 2) s = std::sqrt(s);
+        if (s > 0.0)
+            for (auto& kv : bow) kv.second /= s;
+    }
+    int k = 0;
+    for (auto& kv : bow) { bow_word[k] = kv.first; bow_value[k] = kv.second; k++; }
+    *n_bow = k;
+    int q = 0, o = 0;
+    fv_off[0] = 0;
+    for (auto& kv : fv) {
+        fv_node[q] = kv.first;
+        for (int32_t i : kv.second) fv_idx[o++] = i;
+        fv_off[++q] = o;
+    }
+    *n_fv = q;
     return PPG_OK;
 }
 

@@ -223,4 +223,24 @@ struct FusedMatchArgs {
 hipError_t launch_match_fused(const FusedMatchArgs& a, hipStream_t s);
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s);
 
+// ---- DBoW3 vocabulary tree descent ----
+struct BowArgs {
+    const float* desc;        // [batch][n][dim]
+    size_t stride_batch;      // floats between two batches' descriptor blocks
+    int n;                    // descriptors per batch entry (rows of the output)
+    const int* n_dev;         // optional device-resident counts (entry b at n_dev[b*sn]); rows beyond are left untouched
+    int sn;
+    const float* node_desc;   // [n_nodes][dim]
+    const int* child_off;     // [n_nodes + 1]
+    const int* child_idx;
+    const int* word_id;       // [n_nodes]
+    const double* weight;     // [n_nodes]
+    int dim;
+    int nid_level;            // L - levelsup
+    int32_t* out_word;        // [batch][n]
+    double* out_weight;
+    int32_t* out_node;
+};
+hipError_t launch_bow_transform(const BowArgs& a, int batch, hipStream_t s);
+
 }  // namespace ppg

@@ -2660,4 +2660,57 @@ hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
     return hipGetLastError();
 }
 
+// =====================================================================================
+// DBoW3::Vocabulary::transform(feature, word_id, weight, nid, levelsup) (called for every descriptor of a frame at
+// map/src/Frame.cpp:131 and :338): descend the k-ary tree from the root, at every level to the child whose node
+// descriptor is nearest (squared L2: float differences, float squares, summed in double in component order; the first
+// minimum in child order wins), until a leaf; report the leaf's word and weight and the node passed at level
+// L - levelsup (the root when that is <= 0).  Sixteen lanes per descriptor, a lane per child.
+// =====================================================================================
+__global__ __launch_bounds__(256) void bow_transform_kernel(BowArgs a) {
+    const int b = blockIdx.y;
+    const int n = a.n_dev ? min(a.n, a.n_dev[b * a.sn]) : a.n;
+    const int f = (blockIdx.x * 256 + threadIdx.x) >> 4, gl = threadIdx.x & 15;
+    if (f >= n) return;   // whole 16-lane groups leave together
+    const float* x = a.desc + b * a.stride_batch + (size_t)f * a.dim;
+    int cur = 0, level = 0, nid = 0;
+    for (;;) {
+        level++;
+        const int c0 = a.child_off[cur], nc = a.child_off[cur + 1] - c0;
+        double best = 1.7976931348623157e308;
+        int bpos = 0x7FFFFFFF;
+        for (int t = gl; t < nc; t += 16) {
+            const float* y = a.node_desc + (size_t)a.child_idx[c0 + t] * a.dim;
+            double sqd = 0.0;
+            for (int d = 0; d < a.dim; d++) {
+                const float df = x[d] - y[d];
+                sqd += (double)(df * df);
+            }
+            if (sqd < best) { best = sqd; bpos = t; }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o);
+            const int op = __shfl_xor(bpos, o);
+            if (ob < best || (ob == best && op < bpos)) { best = ob; bpos = op; }
+        }
+        // a node whose children are all farther than DBL_MAX cannot occur; bpos is valid when nc > 0
+        cur = a.child_idx[c0 + bpos];
+        if (level == a.nid_level) nid = cur;
+        if (a.child_off[cur + 1] == a.child_off[cur]) break;   // leaf
+    }
+    if (gl == 0) {
+        const size_t o = (size_t)b * a.n + f;
+        a.out_word[o] = a.word_id[cur];
+        a.out_weight[o] = a.weight[cur];
+        a.out_node[o] = nid;
+    }
+}
+
+hipError_t launch_bow_transform(const BowArgs& a, int batch, hipStream_t s) {
+    if (a.n <= 0 || batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bow_transform_kernel, dim3((a.n * 16 + 255) / 256, batch), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace ppg
