@@ -193,7 +193,9 @@ struct ppg_ctx {
     // matcher scratch (grown on demand)
     DBuf<float> mA, mB, mD, mBest, mSecond, mTopD;
     DBuf<int32_t> mOff, mIdx, mMatch, mTopI;
-    DBuf<uint8_t> mSkip;
+    DBuf<uint8_t> mSkip, mSkipOut, mRowClaims, xArena;
+    std::vector<uint8_t> xHost;      // host image of xArena (ppg_extend_map_matches)
+    bool extend_on_host = false;     // PPG_EXTEND_HOST=1: the host walk (the statement the device walk is checked against)
     DBuf<uint32_t> mClaim;
     DBuf<float> mNorm;
     DBuf<int32_t> mListCnt, mNearLen;
@@ -752,7 +754,7 @@ void ppg_destroy(ppg_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
-                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p,
+                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p, c->mSkipOut.p, c->mRowClaims.p, c->xArena.p,
                   c->voc_desc, c->voc_child_off, c->voc_child_idx, c->voc_word, c->voc_weight};
     for (void* p : ms)
         if (p) (void)hipFree(p);
@@ -813,6 +815,8 @@ static int create_impl(ppg_ctx* c) {
         c->dump_tail = getenv("PPG_DUMP_TAIL");
         const char* mm = getenv("PPG_MATCH_MATRIX");
         c->match_matrix = mm && atoi(mm) != 0;
+        const char* eh = getenv("PPG_EXTEND_HOST");
+        c->extend_on_host = eh && atoi(eh) != 0;
         const char* lh = getenv("PPG_LINES_HOST");
         c->lines_on_host = (lh && atoi(lh) != 0) || c->dump_tail;
         const char* e = getenv("PPG_HOST_THREADS");
@@ -1844,29 +1848,31 @@ int ppg_match_projected(ppg_ctx* c, const ppg_proj_args* a, int32_t* best_idx, f
     HIPCHK(c, hipMemcpyAsync(c->mOff.p, off.data(), sizeof(int32_t) * (n1 + 1), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->mIdx.p, idx.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
     HIPCHK(c, ppg::launch_dist_csr(c->mA.p, n1, c->mB.p, dim, c->mOff.p, c->mIdx.p, c->mD.p, s));
-    std::vector<float> D(nd);
-    HIPCHK(c, hipMemcpyAsync(D.data(), c->mD.p, sizeof(float) * nd, hipMemcpyDeviceToHost, s));
+    // the order-dependent pass (skip rules, first argmin, accept, slot claiming) on the device as well: only the
+    // per-row results come back
+    const bool claims = a->slot_blocked && a->row_claims;
+    rc = grow(c, c->mMatch, n1);
+    if (!rc) rc = grow(c, c->mBest, n1);
+    if (!rc) rc = grow(c, c->mTopI, n1);
+    if (!rc) rc = grow(c, c->mClaim, n2);
+    if (!rc && a->slot_blocked) rc = grow(c, c->mSkip, n2);
+    if (!rc && a->slot_blocked) rc = grow(c, c->mSkipOut, n2);
+    if (!rc && claims) rc = grow(c, c->mRowClaims, n1);
+    if (rc) return rc;
+    if (a->slot_blocked) HIPCHK(c, hipMemcpyAsync(c->mSkip.p, a->slot_blocked, n2, hipMemcpyHostToDevice, s));
+    if (claims) HIPCHK(c, hipMemcpyAsync(c->mRowClaims.p, a->row_claims, n1, hipMemcpyHostToDevice, s));
+    ppg::ProjMatchArgs pm;
+    pm.D = c->mD.p; pm.cand_off = c->mOff.p; pm.cand_idx = c->mIdx.p; pm.n1 = n1; pm.n2 = n2;
+    pm.blocked_in = a->slot_blocked ? c->mSkip.p : nullptr; pm.row_claims = claims ? c->mRowClaims.p : nullptr;
+    pm.th = a->th; pm.ratio = a->ratio; pm.claim = c->mClaim.p; pm.guess = c->mTopI.p; pm.best_idx = c->mMatch.p;
+    pm.best_dist = c->mBest.p; pm.blocked_out = claims ? c->mSkipOut.p : nullptr; pm.n_matches = c->mCount;
+    HIPCHK(c, ppg::launch_match_projected(pm, s));
+    HIPCHK(c, hipMemcpyAsync(best_idx, c->mMatch.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+    if (best_dist) HIPCHK(c, hipMemcpyAsync(best_dist, c->mBest.p, sizeof(float) * n1, hipMemcpyDeviceToHost, s));
+    if (claims) HIPCHK(c, hipMemcpyAsync(a->slot_blocked, c->mSkipOut.p, n2, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_mcount, c->mCount, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    // the reference's loop, with table look-ups in place of DescriptorDistance
-    int nm = 0;
-    for (int i = 0; i < n1; i++) {
-        float best = 1e6f, second = 1e6f;
-        int bi = -1;
-        for (int k = off[i]; k < off[i + 1]; k++) {
-            const int j = idx[k];
-            if (a->slot_blocked && a->slot_blocked[j]) continue;
-            const float d = D[k];
-            if (d < best) { second = best; best = d; bi = j; }
-            else if (d < second) second = d;
-        }
-        if (best_dist) best_dist[i] = best;
-        if (best <= a->th) {
-            if (a->ratio > 0.f && best > a->ratio * second) continue;
-            best_idx[i] = bi;
-            nm++;
-            if (a->slot_blocked && a->row_claims && a->row_claims[i]) a->slot_blocked[bi] = 1;
-        }
-    }
+    const int nm = c->h_mcount[0];
     if (n_matches) *n_matches = nm;
     return PPG_OK;
 }
@@ -2011,36 +2017,15 @@ int ppg_profile_read(ppg_ctx* c, double* ms, long long* launches) {
     return PPG_OK;
 }
 
-int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgraph* g, const float* desc,
-                           const float* pos_un, int n, const uint32_t* edge_idx, int n_edges, const int32_t* conn_off,
-                           const uint32_t* conn_idx, uint8_t* tracked, int32_t* frame_mp, int32_t* frame_me,
-                           int* n_matches) {
-    if (!c) return PPG_EINVAL;
-    if (!g || g->m < 0 || n < 0 || n_edges < 0 || (n && (!desc || !pos_un || !conn_off || !frame_mp)) ||
-        (g->m && (!g->desc || !g->proj || !g->viewcos || !g->in_view || !g->bad || !g->nobs || !g->edge_off || !tracked)))
-        return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad argument");
-    if (n_matches) *n_matches = 0;
+// The walk of Matcher::ExtendMapMatches on the host, every distance taken from one m x n GPU distance matrix: the
+// statement the device walk (extend_map_matches_kernel) is checked against, and the path for problems beyond that
+// kernel's limits (more than 8192 map points, 4096 key points, 64 edges at a point).
+static int extend_map_matches_host(ppg_ctx* c, float nnratio, float th, const ppg_mapgraph* g, const float* desc,
+                                   const float* pos_un, int n, const uint32_t* edge_idx, int n_edges, const int32_t* conn_off,
+                                   const uint32_t* conn_idx, uint8_t* tracked, int32_t* frame_mp, int32_t* frame_me,
+                                   int* n_matches) {
+    (void)n_edges;
     const int m = g->m;
-    if (m == 0 || n == 0) return PPG_OK;
-    {   // every id that is used as an index below
-        const int ne = g->edge_off[m];
-        if (g->edge_off[0] != 0 || ne < 0 || (ne && (!g->edge_other || !g->edge_ok || !g->edge_id)))
-            return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad edge lists");
-        for (int i = 0; i < m; i++)
-            if (g->edge_off[i + 1] < g->edge_off[i]) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_off must be non-decreasing");
-        for (int k = 0; k < ne; k++)
-            if (g->edge_other[k] < -1 || g->edge_other[k] >= m) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_other[%d] out of range", k);
-        for (int i = 0; i < n; i++)
-            if (frame_mp[i] < -1 || frame_mp[i] >= m) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: frame_mp[%d] out of range", i);
-        if (conn_off[0] != 0 || conn_off[n] < 0 || (conn_off[n] && (!conn_idx || !edge_idx)))
-            return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad key-edge lists");
-        for (int i = 0; i < n; i++)
-            if (conn_off[i + 1] < conn_off[i]) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: conn_off must be non-decreasing");
-        for (int k = 0; k < conn_off[n]; k++)
-            if ((int)conn_idx[k] >= n_edges) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: conn_idx[%d] out of range", k);
-        for (int e = 0; e < 2 * n_edges; e++)
-            if ((int)edge_idx[e] >= n) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_idx[%d] out of range", e);
-    }
     const float TH_HIGH = 0.8f;  // matching/src/Matcher.cpp:12
     // every DescriptorDistance the walk can ask for is an entry of the m x n matrix: one GPU pass
     std::vector<float> D((size_t)m * n);
@@ -2120,6 +2105,115 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
     }
     ppg_grid_free(grid);
     if (n_matches) *n_matches = nmatches;
+    return PPG_OK;
+}
+
+int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgraph* g, const float* desc,
+                           const float* pos_un, int n, const uint32_t* edge_idx, int n_edges, const int32_t* conn_off,
+                           const uint32_t* conn_idx, uint8_t* tracked, int32_t* frame_mp, int32_t* frame_me,
+                           int* n_matches) {
+    if (!c) return PPG_EINVAL;
+    if (!g || g->m < 0 || n < 0 || n_edges < 0 || (n && (!desc || !pos_un || !conn_off || !frame_mp)) ||
+        (g->m && (!g->desc || !g->proj || !g->viewcos || !g->in_view || !g->bad || !g->nobs || !g->edge_off || !tracked)))
+        return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad argument");
+    if (n_matches) *n_matches = 0;
+    const int m = g->m;
+    if (m == 0 || n == 0) return PPG_OK;
+    {   // every id that is used as an index below
+        const int ne = g->edge_off[m];
+        if (g->edge_off[0] != 0 || ne < 0 || (ne && (!g->edge_other || !g->edge_ok || !g->edge_id)))
+            return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad edge lists");
+        for (int i = 0; i < m; i++)
+            if (g->edge_off[i + 1] < g->edge_off[i]) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_off must be non-decreasing");
+        for (int k = 0; k < ne; k++)
+            if (g->edge_other[k] < -1 || g->edge_other[k] >= m) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_other[%d] out of range", k);
+        for (int i = 0; i < n; i++)
+            if (frame_mp[i] < -1 || frame_mp[i] >= m) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: frame_mp[%d] out of range", i);
+        if (conn_off[0] != 0 || conn_off[n] < 0 || (conn_off[n] && (!conn_idx || !edge_idx)))
+            return fail(c, PPG_EINVAL, "ppg_extend_map_matches: bad key-edge lists");
+        for (int i = 0; i < n; i++)
+            if (conn_off[i + 1] < conn_off[i]) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: conn_off must be non-decreasing");
+        for (int k = 0; k < conn_off[n]; k++)
+            if ((int)conn_idx[k] >= n_edges) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: conn_idx[%d] out of range", k);
+        for (int e = 0; e < 2 * n_edges; e++)
+            if ((int)edge_idx[e] >= n) return fail(c, PPG_EINVAL, "ppg_extend_map_matches: edge_idx[%d] out of range", e);
+    }
+    if (c->extend_on_host || m > 8192 || n > 4096)
+        return extend_map_matches_host(c, nnratio, th, g, desc, pos_un, n, edge_idx, n_edges, conn_off, conn_idx, tracked, frame_mp, frame_me, n_matches);
+    // ---- device walk ----
+    std::vector<int> cands;  // Matcher.cpp:210-222
+    for (int i = 0; i < m; i++)
+        if (!g->bad[i] && g->in_view[i]) cands.push_back(i);
+    std::sort(cands.begin(), cands.end(), [g](int a, int b) {
+        return (g->edge_off[a + 1] - g->edge_off[a]) > (g->edge_off[b + 1] - g->edge_off[b]);
+    });
+    const int ncand = (int)cands.size();
+    if (ncand == 0) return PPG_OK;
+    // the window of every candidate (:240-247): it depends on the projection only, not on the walk
+    ppg_grid* grid = ppg_grid_build(&c->cfg, pos_un, n);
+    if (!grid) return fail(c, PPG_ENOMEM, "grid allocation failed");
+    std::vector<int32_t> woff(ncand + 1, 0), widx, tmp(n);
+    for (int k = 0; k < ncand; k++) {
+        const int mp = cands[k];
+        float r = th;
+        if (g->viewcos[mp] > 0.998) r *= 2.5; else r *= 4.0;
+        const int cnt = ppg_features_in_area(grid, g->proj[2 * mp], g->proj[2 * mp + 1], r, tmp.data(), n);
+        widx.insert(widx.end(), tmp.begin(), tmp.begin() + cnt);
+        woff[k + 1] = (int32_t)widx.size();
+    }
+    ppg_grid_free(grid);
+    const size_t nw = widx.size(), ne = (size_t)g->edge_off[m], nconn = (size_t)conn_off[n];
+    // one packed upload: every array at a 256-byte aligned offset of one host block
+    struct Part { const void* src; size_t bytes; size_t off; };
+    std::vector<Part> parts;
+    size_t total = 0;
+    auto add = [&](const void* src, size_t bytes) { parts.push_back({src, bytes, total}); total += (bytes + 255) / 256 * 256; return parts.size() - 1; };
+    const size_t iMdesc = add(g->desc, sizeof(float) * 256 * m), iFdesc = add(desc, sizeof(float) * 256 * n);
+    const size_t iCands = add(cands.data(), sizeof(int32_t) * ncand), iWoff = add(woff.data(), sizeof(int32_t) * (ncand + 1));
+    const size_t iWidx = add(widx.data(), sizeof(int32_t) * nw), iBad = add(g->bad, m), iNobs = add(g->nobs, sizeof(int32_t) * m);
+    const size_t iEoff = add(g->edge_off, sizeof(int32_t) * (m + 1)), iEid = add(g->edge_id, sizeof(int32_t) * ne);
+    const size_t iEoth = add(g->edge_other, sizeof(int32_t) * ne), iEok = add(g->edge_ok, ne);
+    const size_t iKe = add(edge_idx, sizeof(uint32_t) * 2 * n_edges), iCoff = add(conn_off, sizeof(int32_t) * (n + 1));
+    const size_t iCidx = add(conn_idx, sizeof(uint32_t) * nconn), iTr = add(tracked, m), iFmp = add(frame_mp, sizeof(int32_t) * n);
+    const size_t iFme = add(frame_me, frame_me ? sizeof(int32_t) * n_edges : 0);
+    const size_t oWdist = total; total += (sizeof(float) * nw + 255) / 256 * 256;
+    const size_t oOut = total; total += 256;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    int rc = grow(c, c->xArena, total);
+    if (rc) return rc;
+    c->xHost.resize(total);
+    for (const Part& p : parts)
+        if (p.bytes) memcpy(c->xHost.data() + p.off, p.src, p.bytes);
+    hipStream_t s = c->post;
+    uint8_t* base = c->xArena.p;
+    HIPCHK(c, hipMemcpyAsync(base, c->xHost.data(), oWdist, hipMemcpyHostToDevice, s));
+    auto dp = [&](size_t i) { return base + parts[i].off; };
+    HIPCHK(c, ppg::launch_dist_csr_rows((const float*)dp(iMdesc), (const int32_t*)dp(iCands), ncand, (const float*)dp(iFdesc),
+                                        (const int32_t*)dp(iWoff), (const int32_t*)dp(iWidx), (float*)(base + oWdist), s));
+    ppg::ExtendArgs x;
+    x.m = m; x.n = n; x.n_edges = n_edges; x.ncand = ncand;
+    x.cands = (const int32_t*)dp(iCands); x.win_off = (const int32_t*)dp(iWoff); x.win_idx = (const int32_t*)dp(iWidx);
+    x.win_dist = (const float*)(base + oWdist); x.mdesc = (const float*)dp(iMdesc); x.fdesc = (const float*)dp(iFdesc);
+    x.bad = (const uint8_t*)dp(iBad); x.nobs = (const int32_t*)dp(iNobs); x.edge_off = (const int32_t*)dp(iEoff);
+    x.edge_id = (const int32_t*)dp(iEid); x.edge_other = (const int32_t*)dp(iEoth); x.edge_ok = (const uint8_t*)dp(iEok);
+    x.key_edge_idx = (const uint32_t*)dp(iKe); x.conn_off = (const int32_t*)dp(iCoff); x.conn_idx = (const uint32_t*)dp(iCidx);
+    x.tracked = (uint8_t*)dp(iTr); x.frame_mp = (int32_t*)dp(iFmp); x.frame_me = frame_me ? (int32_t*)dp(iFme) : nullptr;
+    x.nnratio = nnratio; x.out = (int*)(base + oOut);
+    HIPCHK(c, ppg::launch_extend_map_matches(x, s));
+    // results land in the host block first: a walk that exceeded the kernel's limits is redone on the host from the
+    // caller's untouched arrays
+    HIPCHK(c, hipMemcpyAsync(c->xHost.data() + parts[iTr].off, dp(iTr), m, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->xHost.data() + parts[iFmp].off, dp(iFmp), sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    if (frame_me && n_edges) HIPCHK(c, hipMemcpyAsync(c->xHost.data() + parts[iFme].off, dp(iFme), sizeof(int32_t) * n_edges, hipMemcpyDeviceToHost, s));
+    int out[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(out, base + oOut, sizeof(out), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (out[1])
+        return extend_map_matches_host(c, nnratio, th, g, desc, pos_un, n, edge_idx, n_edges, conn_off, conn_idx, tracked, frame_mp, frame_me, n_matches);
+    memcpy(tracked, c->xHost.data() + parts[iTr].off, m);
+    memcpy(frame_mp, c->xHost.data() + parts[iFmp].off, sizeof(int32_t) * n);
+    if (frame_me && n_edges) memcpy(frame_me, c->xHost.data() + parts[iFme].off, sizeof(int32_t) * n_edges);
+    if (n_matches) *n_matches = out[0];
     return PPG_OK;
 }
 

@@ -223,6 +223,52 @@ struct FusedMatchArgs {
 hipError_t launch_match_fused(const FusedMatchArgs& a, hipStream_t s);
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s);
 
+// ---- order-dependent pass of the projection matchers ----
+struct ProjMatchArgs {
+    const float* D;            // distance of every listed candidate
+    const int32_t* cand_off;   // [n1 + 1]
+    const int32_t* cand_idx;   // slots
+    int n1, n2;
+    const uint8_t* blocked_in; // [n2] or nullptr
+    const uint8_t* row_claims; // [n1] or nullptr
+    float th, ratio;
+    uint32_t* claim;           // [n2] work
+    int32_t* guess;            // [n1] work
+    int32_t* best_idx;         // [n1]
+    float* best_dist;          // [n1]
+    uint8_t* blocked_out;      // [n2] or nullptr
+    int* n_matches;
+};
+hipError_t launch_match_projected(const ProjMatchArgs& a, hipStream_t s);
+
+// ---- Matcher::ExtendMapMatches on the device ----
+struct ExtendArgs {
+    int m, n, n_edges, ncand;
+    const int32_t* cands;          // trackable map points in visiting order (sorted by edge count on the host)
+    const int32_t* win_off;        // [ncand + 1] window of every candidate: key points in GetFeaturesInArea order
+    const int32_t* win_idx;
+    const float* win_dist;         // their descriptor distances
+    const float* mdesc;            // [m][256]
+    const float* fdesc;            // [n][256]
+    const uint8_t* bad;            // [m]
+    const int32_t* nobs;           // [m]
+    const int32_t* edge_off;       // [m + 1] map edges per point
+    const int32_t* edge_id;
+    const int32_t* edge_other;
+    const uint8_t* edge_ok;
+    const uint32_t* key_edge_idx;  // [n_edges][2]
+    const int32_t* conn_off;       // [n + 1]
+    const uint32_t* conn_idx;
+    uint8_t* tracked;              // [m] in/out
+    int32_t* frame_mp;             // [n] in/out
+    int32_t* frame_me;             // [n_edges] in/out or nullptr
+    float nnratio;
+    int* out;                      // [0] the reference's return value, [1] set when a degree exceeded the kernel's limits
+};
+hipError_t launch_extend_map_matches(const ExtendArgs& a, hipStream_t s);
+hipError_t launch_dist_csr_rows(const float* A, const int32_t* rows, int nrows, const float* B, const int32_t* cand_off,
+                                const int32_t* cand_idx, float* Dc, hipStream_t s);
+
 // ---- DBoW3 vocabulary tree descent ----
 struct BowArgs {
     const float* desc;        // [batch][n][dim]

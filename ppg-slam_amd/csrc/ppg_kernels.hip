@@ -2713,4 +2713,201 @@ hipError_t launch_bow_transform(const BowArgs& a, int batch, hipStream_t s) {
     return hipGetLastError();
 }
 
+// =====================================================================================
+// The inner loop shared by Matcher::SearchByProjection (matching/src/Matcher.cpp:31-87, :89-189, :479-568) and
+// Matcher::Fuse (:897-1036, :1038-1135) with its order dependence: rows are visited in order, a row skips blocked
+// slots, takes the first argmin of its candidates, accepts by threshold (and ratio), and an accepted row that claims
+// blocks its slot for the rows after it.  As for the initialisation matcher, the sequential result is the fixed point
+// of "every row recomputes its match from the claims of the rows before it" (triangular system): a few parallel
+// rounds instead of one sequential pass.  One work-group; rows and candidates are strided over its threads.
+// =====================================================================================
+__global__ __launch_bounds__(1024) void match_projected_kernel(ProjMatchArgs a) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.n1; i += 1024) a.guess[i] = -1;
+    __syncthreads();
+    for (int round = 0; round <= a.n1; round++) {
+        for (int j = tid; j < a.n2; j += 1024) a.claim[j] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int i = tid; i < a.n1; i += 1024)
+            if (a.guess[i] >= 0 && a.row_claims && a.row_claims[i]) atomicMin(&a.claim[a.guess[i]], (uint32_t)i);
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < a.n1; i += 1024) {
+            float best = 1e6f, second = 1e6f;
+            int bi = -1;
+            for (int k = a.cand_off[i]; k < a.cand_off[i + 1]; k++) {
+                const int j = a.cand_idx[k];
+                if ((a.blocked_in && a.blocked_in[j]) || a.claim[j] < (uint32_t)i) continue;
+                const float d = a.D[k];
+                if (d < best) { second = best; best = d; bi = j; }
+                else if (d < second) second = d;
+            }
+            int m = -1;
+            if (best <= a.th && !(a.ratio > 0.f && best > a.ratio * second)) m = bi;
+            a.best_dist[i] = best;
+            changed |= m != a.guess[i];
+            a.best_idx[i] = m;
+        }
+        const int any = __syncthreads_count(changed);
+        for (int i = tid; i < a.n1; i += 1024) a.guess[i] = a.best_idx[i];
+        __syncthreads();
+        if (!any) break;
+    }
+    // slots blocked afterwards: the given ones and every claimed one (claim[] holds the final claims: it was rebuilt from
+    // the final guesses at the top of the last round)
+    int cnt = 0;
+    for (int i = tid; i < a.n1; i += 1024) cnt += a.guess[i] >= 0;
+    if (a.blocked_out)
+        for (int j = tid; j < a.n2; j += 1024) a.blocked_out[j] = (uint8_t)((a.blocked_in && a.blocked_in[j]) || a.claim[j] != 0xFFFFFFFFu);
+    __shared__ int tot;
+    if (tid == 0) tot = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & 63) == 0) atomicAdd(&tot, cnt);
+    __syncthreads();
+    if (tid == 0) *a.n_matches = tot;
+}
+
+hipError_t launch_match_projected(const ProjMatchArgs& a, hipStream_t s) {
+    if (a.n1 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(match_projected_kernel, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Matcher::ExtendMapMatches (matching/src/Matcher.cpp:203-381), the point-pair-graph matcher, by ONE wave.
+//
+// The loop is sequential by nature: every accepted map point changes F.mvpMapPoints, which the skip rule of the next
+// window search reads (:253-255), and the seed growing (:287-377) walks the two graphs breadth first, assigning as it
+// goes.  The distances of the window searches do not depend on that state and arrive precomputed (one parallel
+// launch over all windows); the weights of a seed's small (map edges) x (key edges) matrix are evaluated when the
+// seed is popped, a lane per pair.  Mutable state lives in LDS: tracked flags, F.mvpMapPoints and the seed queue (every
+// push marks another map point tracked, so one walk never pushes more than m entries).
+// =====================================================================================
+constexpr int EX_MAXM = 8192, EX_MAXN = 4096, EX_MAXDEG = 64, EX_MAXW = 1024;
+
+__global__ __launch_bounds__(64) void extend_map_matches_kernel(ExtendArgs a) {
+    __shared__ uint8_t tracked[EX_MAXM];
+    __shared__ int32_t fmp[EX_MAXN];
+    __shared__ float W[EX_MAXW];
+    __shared__ uint16_t queue[EX_MAXM + 1];
+    __shared__ uint8_t lxs[EX_MAXDEG], rowused[EX_MAXDEG], colused[EX_MAXDEG];
+    const int lane = threadIdx.x;
+    const float TH_HIGH = 0.8f;   // matching/src/Matcher.cpp:12
+    for (int k = lane; k < a.m; k += 64) tracked[k] = a.tracked[k];
+    for (int k = lane; k < a.n; k += 64) fmp[k] = a.frame_mp[k];
+    __syncthreads();
+    int nmatches = 0;
+    bool overflow = false;
+    for (int c = 0; c < a.ncand && !overflow; c++) {
+        const int mp = a.cands[c];
+        if (tracked[mp] || a.bad[mp]) continue;                                   // :227
+        const int w0 = a.win_off[c], cnt = a.win_off[c + 1] - w0;
+        if (cnt == 0) continue;
+        Best2 v = {1e6f, 1e6f, -1, -1};
+        for (int k = lane; k < cnt; k += 64) {                                    // :251-270
+            const int id = a.win_idx[w0 + k];
+            const int cur = fmp[id];
+            if (cur >= 0 && a.nobs[cur] > 0) continue;
+            const float d = a.win_dist[w0 + k];
+            if (d < v.b) { v.b2 = v.b; v.b = d; v.pos = k; v.idx = id; }
+            else if (d < v.b2) v.b2 = d;
+        }
+        v = best2_wave(v);
+        if (v.b > TH_HIGH && v.b > a.nnratio * v.b2) continue;                    // :276
+        if (v.idx < 0) continue;   // every candidate of the window was skipped (the reference would index with -1, :279)
+        if (lane == 0) { fmp[v.idx] = mp; tracked[mp] = 1; queue[0] = (uint16_t)v.idx; }
+        nmatches++;
+        __syncthreads();
+        int qh = 0, qt = 1;
+        const int me0 = a.edge_off[mp], nme = a.edge_off[mp + 1] - me0;          // the map side stays the first seed's point (:296)
+        while (qh < qt) {
+            const int keyID = queue[qh];
+            qh++;
+            const int ke0 = a.conn_off[keyID], nke = a.conn_off[keyID + 1] - ke0;
+            if (nme == 0 || nke == 0) continue;
+            if (nme > EX_MAXDEG || nke > EX_MAXDEG) { overflow = true; break; }
+            // lx: the map edges that are usable, in order
+            const bool okrow = lane < nme && a.edge_ok[me0 + lane] && a.edge_other[me0 + lane] >= 0;
+            const unsigned long long mrow = __ballot(okrow);
+            const int nlx = __popcll(mrow);
+            if (okrow) lxs[__popcll(mrow & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            if (lane < EX_MAXDEG) { rowused[lane] = 0; colused[lane] = 0; }
+            const int P = nlx * nke;
+            if (P > EX_MAXW) { overflow = true; break; }
+            __syncthreads();
+            auto key_other = [&](uint32_t e) { return a.key_edge_idx[2 * e] == (uint32_t)keyID ? a.key_edge_idx[2 * e + 1] : a.key_edge_idx[2 * e]; };
+            for (int p = lane; p < P; p += 64) {                                  // :323-339
+                const int ip = p / nke, jp = p - ip * nke;
+                const int mpo = a.edge_other[me0 + lxs[ip]];
+                const uint32_t ko = key_other(a.conn_idx[ke0 + jp]);
+                W[p] = mpo == fmp[ko] ? -1.f : chain_distance(a.mdesc + (size_t)mpo * 256, a.fdesc + (size_t)ko * 256);
+            }
+            __syncthreads();
+            for (;;) {                                                             // :341-376
+                float bw = 1e6f;
+                int bp = 0x7FFFFFFF;
+                for (int p = lane; p < P; p += 64) {
+                    const int ip = p / nke, jp = p - ip * nke;
+                    if (rowused[ip] || colused[jp]) continue;
+                    if (W[p] < bw) { bw = W[p]; bp = p; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ow = __shfl_xor(bw, o);
+                    const int op = __shfl_xor(bp, o);
+                    if (ow < bw || (ow == bw && op < bp)) { bw = ow; bp = op; }
+                }
+                if (bw > TH_HIGH || bp == 0x7FFFFFFF) break;
+                const int ip = bp / nke, jp = bp - ip * nke;
+                const int mi = lxs[ip];
+                const int mpo = a.edge_other[me0 + mi];
+                const uint32_t keyEdge = a.conn_idx[ke0 + jp];
+                const uint32_t ko = key_other(keyEdge);
+                const bool take = !(mpo < 0 || a.bad[mpo] || tracked[mpo]);
+                __syncthreads();
+                if (lane == 0) {
+                    rowused[ip] = 1; colused[jp] = 1;
+                    if (take) {
+                        fmp[ko] = mpo;
+                        if (a.frame_me) a.frame_me[keyEdge] = a.edge_id[me0 + mi];
+                        tracked[mpo] = 1;
+                        queue[qt] = (uint16_t)ko;
+                    }
+                }
+                if (take) qt++;
+                __syncthreads();
+            }
+        }
+        nmatches++;   // counted twice per accepted seed (:281, :378)
+    }
+    __syncthreads();
+    for (int k = lane; k < a.m; k += 64) a.tracked[k] = tracked[k];
+    for (int k = lane; k < a.n; k += 64) a.frame_mp[k] = fmp[k];
+    if (lane == 0) { a.out[0] = nmatches; a.out[1] = overflow ? 1 : 0; }
+}
+
+hipError_t launch_extend_map_matches(const ExtendArgs& a, hipStream_t s) {
+    if (a.m > EX_MAXM || a.n > EX_MAXN) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(extend_map_matches_kernel, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// distances of CSR candidate lists whose rows are picked from A by an index: Dc[off[r] + k] = |A[rows[r]] - B[idx[off[r]+k]]|
+__global__ __launch_bounds__(256) void dist_csr_rows_kernel(const float* __restrict__ A, const int32_t* __restrict__ rows, int nrows,
+                                                            const float* __restrict__ B, const int32_t* __restrict__ cand_off,
+                                                            const int32_t* __restrict__ cand_idx, float* __restrict__ Dc) {
+    const int r = blockIdx.x;
+    if (r >= nrows) return;
+    const float* x = A + (size_t)rows[r] * 256;
+    for (int k = cand_off[r] + threadIdx.x; k < cand_off[r + 1]; k += 256) Dc[k] = chain_distance(x, B + (size_t)cand_idx[k] * 256);
+}
+
+hipError_t launch_dist_csr_rows(const float* A, const int32_t* rows, int nrows, const float* B, const int32_t* cand_off,
+                                const int32_t* cand_idx, float* Dc, hipStream_t s) {
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dist_csr_rows_kernel, dim3(nrows), dim3(256), 0, s, A, rows, nrows, B, cand_off, cand_idx, Dc);
+    return hipGetLastError();
+}
+
 }  // namespace ppg

@@ -844,3 +844,33 @@ def test_waited_results_survive_the_next_submit(pkg, synth):
                 assert np.array_equal(r[k], s[k], equal_nan=True), (t, k)
     for t in range(4):
         ctx.wait_batch()
+
+
+def test_extend_map_matches_device_walk(pkg, orc, synth, monkeypatch):
+    """The point-pair-graph matcher as one wave on the device against the oracle and against the host walk
+    (PPG_EXTEND_HOST=1), on dense frames with many map points and edges; then a graph whose degrees exceed the
+    kernel's limits, which must fall back to the host walk and still agree."""
+    H, W = 480, 640
+    ctx = get_ctx(pkg, W, H, 1024)
+    cfg = orc.default_cfg(W, H, 1024)
+    r = ctx.extract(synth.make_frame(H, W, 11, 0, "dense"))
+    monkeypatch.setenv("PPG_EXTEND_HOST", "1")
+    host = pkg.Context(pkg.default_config(W, H, max_num=1024))
+    monkeypatch.delenv("PPG_EXTEND_HOST")
+    rng = np.random.default_rng(15)
+    for trial, (m, nedges) in enumerate(((800, 1500), (1500, 4000), (300, 9000))):
+        g = random_map_graph(rng, r["desc"], r["un"], min(m, r["n"]), nedges)
+        mm = g["desc"].shape[0]
+        tracked = (rng.random(mm) < 0.05).astype(np.uint8)
+        fmp = np.full(r["n"], -1, np.int32)
+        pre = rng.choice(r["n"], size=40, replace=False)
+        fmp[pre] = rng.integers(0, mm, 40)
+        fme = np.full(r["n_edges"], -1, np.int32)
+        args = (0.8, 4.0 + 3 * trial, g, r["desc"], r["un"], r["edge_idx"], r["conn_off"], r["conn_idx"], tracked, fmp, fme)
+        co, to, po, eo = orc.extend_map_matches(cfg, *args)
+        cg, tg, pg, eg = ctx.extend_map_matches(*args)
+        ch, th_, ph, eh = host.extend_map_matches(*args)
+        assert cg == co == ch and np.array_equal(tg, to) and np.array_equal(pg, po) and np.array_equal(eg, eo), trial
+        assert np.array_equal(th_, to) and np.array_equal(ph, po) and np.array_equal(eh, eo)
+        assert co > 100 and (eo >= 0).sum() > 0
+    host.close()
