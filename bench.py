@@ -145,6 +145,69 @@ def batch_sweep(pkg, synth, H, W, args, device_id):
     return out
 
 
+def matcher_timings(pkg, synth, H, W, args, device_id):
+    """Every matcher entry point once on a realistic problem (two consecutive dense frames with JUNCTION_MAX_NUM key
+    points, a synthetic local map), wall time of the blocking C-ABI call including its uploads, with the CPU oracle's
+    time for the same call beside it where the oracle restates it.  Milliseconds, best of 5."""
+    from oracle import oracle as orc
+    ctx = pkg.Context(pkg.default_config(W, H, max_batch=2, max_num=args.max_num, device_id=device_id))
+    cfg = orc.default_cfg(W, H, args.max_num)
+    scene = synth.make_scene(H, W, 11, args.kind)
+    f0, f1 = ctx.extract_batch([synth.frame_from_scene(scene, H, W, 0), synth.frame_from_scene(scene, H, W, 1)])
+    rng = np.random.default_rng(1)
+
+    def best(fn, reps=5):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return round(min(ts) * 1e3, 4)
+
+    out = {"problem": f"frames with {f0['n']} and {f1['n']} key points, {f1['n_edges']} key edges; local map of 600 points and 1500 edges",
+           "note": "blocking calls with host pointers: uploads, kernels, downloads; cpu = the oracle's restatement on one core"}
+    out["SearchForInitialization_window50"] = {
+        "gpu": best(lambda: ctx.search_for_initialization(0.9, f0["desc"], f1["desc"], f1["un"], f0["un"], 50)),
+        "cpu": best(lambda: orc.search_for_initialization(cfg, 0.9, f0["desc"], f1["desc"], f1["un"], f0["un"], 50), 2)}
+    out["SearchForInitialization_all_pairs"] = {
+        "gpu": best(lambda: ctx.search_for_initialization(0.9, f0["desc"], f1["desc"], f1["un"], f0["un"], 0)),
+        "gpu_resident": best(lambda: ctx.match_frames(0, 1, f0["n"], 0.9)),
+        "cpu": best(lambda: orc.search_for_initialization(cfg, 0.9, f0["desc"], f1["desc"], f1["un"], f0["un"], 0), 2)}
+    g = synth.random_map_graph(rng, f1["desc"], f1["un"], min(600, f1["n"]), 1500)
+    m = g["desc"].shape[0]
+    xargs = (0.8, 5.0, g, f1["desc"], f1["un"], f1["edge_idx"], f1["conn_off"], f1["conn_idx"], np.zeros(m, np.uint8),
+             np.full(f1["n"], -1, np.int32), np.full(f1["n_edges"], -1, np.int32))
+    out["ExtendMapMatches"] = {"gpu": best(lambda: ctx.extend_map_matches(*xargs)),
+                               "cpu": best(lambda: orc.extend_map_matches(cfg, *xargs), 2),
+                               "matches": int(ctx.extend_map_matches(*xargs)[0])}
+    # the windowed argmin every projection matcher and Fuse run (ppg_match_projected's inner search), as candidate lists
+    off, idx = [0], []
+    for i in range(f0["n"]):
+        idx.extend(orc.features_in_area(cfg, f1["un"], float(f0["un"][i, 0]), float(f0["un"][i, 1]), 15.0).tolist())
+        off.append(len(idx))
+    off, idx = np.array(off, np.int32), np.array(idx if idx else [0], np.int32)
+    out["windowed_nearest_neighbour_r15"] = {"gpu": best(lambda: ctx.match_nn(f0["desc"], f1["desc"], off, idx, None, 0.8, 0.0, pkg.MATCH_PLAIN)),
+                                             "candidates": int(off[-1])}
+    segs = np.arange(0, f1["n"] + 1, 8, dtype=np.int32)
+    out["ComputeDistinctiveDescriptors_8obs"] = {
+        "gpu": best(lambda: ctx.distinctive_descriptors(f1["desc"][:segs[-1]], segs)),
+        "cpu": best(lambda: [orc.distinctive_descriptor(f1["desc"][segs[p]:segs[p + 1]]) for p in range(len(segs) - 1)], 2),
+        "map_points": int(len(segs) - 1)}
+    import tempfile
+    from oracle import vocab as ov
+    with tempfile.TemporaryDirectory() as td:
+        vp = os.path.join(td, "voc.bin")
+        ov.write_synthetic(vp, k=9, L=3, dim=256, seed=7)
+        o, v = ov.load(vp), pkg.Vocabulary(vp)
+        out["BoW_transform_k9_L3"] = {"gpu": best(lambda: pkg.bow_transform(ctx, v, f1["desc"], 4)),
+                                      "gpu_resident_2_frames": best(lambda: pkg.bow_transform_batch(ctx, v, 2, 4)),
+                                      "cpu": best(lambda: orc.bow_transform(o, f1["desc"], 4), 2)}
+        v.close()
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +361,12 @@ def main():
     sweep = None
     if world == 1 and not args.no_sweep:
         sweep = batch_sweep(pkg, synth, H, W, args, local_rank)
+    matchers = None
+    if world == 1 and not args.no_sweep and not args.no_cpu_baseline:
+        try:
+            matchers = matcher_timings(pkg, synth, H, W, args, local_rank)
+        except Exception as e:   # a report beside the benchmark, never a reason to lose its line
+            matchers = {"error": str(e)[:300]}
 
     # Fourth pass (fp32 runs only): the same step with the 3x3 convolutions in the fp16 hi/lo-split mode
     # (ppg_config.precision = 3), reported beside the number of record, never as it.
@@ -370,6 +439,7 @@ def main():
             "extract_only_frames_per_s": round(extract_only_fps, 1),
             "with_upload": with_upload,
             "batch_sweep": sweep,
+            "matchers_ms": matchers,
             "f16_split_mode": split,
             "device_ms_note": f"from a second pass of {nb} steps with events around every kernel class (not the timed region)",
         }

@@ -2199,6 +2199,14 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
     x.key_edge_idx = (const uint32_t*)dp(iKe); x.conn_off = (const int32_t*)dp(iCoff); x.conn_idx = (const uint32_t*)dp(iCidx);
     x.tracked = (uint8_t*)dp(iTr); x.frame_mp = (int32_t*)dp(iFmp); x.frame_me = frame_me ? (int32_t*)dp(iFme) : nullptr;
     x.nnratio = nnratio; x.out = (int*)(base + oOut);
+    if ((size_t)m * n <= ((size_t)1 << 24)) {
+        // every weight a seed can ask for, evaluated in parallel up front (it stays on the device): the walk then looks a
+        // weight up instead of running a 256-step chain inside its sequential loop
+        rc = grow(c, c->mD, (size_t)m * n);
+        if (rc) return rc;
+        HIPCHK(c, ppg::launch_dist_matrix(x.mdesc, m, x.fdesc, n, 256, c->mD.p, n, s));
+        x.Dfull = c->mD.p;
+    }
     HIPCHK(c, ppg::launch_extend_map_matches(x, s));
     // results land in the host block first: a walk that exceeded the kernel's limits is redone on the host from the
     // caller's untouched arrays

@@ -250,6 +250,7 @@ struct ExtendArgs {
     const float* win_dist;         // their descriptor distances
     const float* mdesc;            // [m][256]
     const float* fdesc;            // [n][256]
+    const float* Dfull = nullptr;  // optional [m][n] distance matrix (same chain): seed weights are looked up instead of evaluated
     const uint8_t* bad;            // [m]
     const int32_t* nobs;           // [m]
     const int32_t* edge_off;       // [m + 1] map edges per point

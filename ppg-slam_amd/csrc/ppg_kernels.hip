@@ -2841,7 +2841,8 @@ __global__ __launch_bounds__(64) void extend_map_matches_kernel(ExtendArgs a) {
                 const int ip = p / nke, jp = p - ip * nke;
                 const int mpo = a.edge_other[me0 + lxs[ip]];
                 const uint32_t ko = key_other(a.conn_idx[ke0 + jp]);
-                W[p] = mpo == fmp[ko] ? -1.f : chain_distance(a.mdesc + (size_t)mpo * 256, a.fdesc + (size_t)ko * 256);
+                W[p] = mpo == fmp[ko] ? -1.f
+                                      : (a.Dfull ? a.Dfull[(size_t)mpo * a.n + ko] : chain_distance(a.mdesc + (size_t)mpo * 256, a.fdesc + (size_t)ko * 256));
             }
             __syncthreads();
             for (;;) {                                                             // :341-376

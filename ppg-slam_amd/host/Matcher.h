@@ -163,6 +163,74 @@ public:
         return nmatches;
     }
 
+    // matching/src/Matcher.cpp:89-189 (no call site in the reference).  map: the candidate points with their
+    // mTrackProjX/Y, mTrackViewCos, mbTrackInView; F.mvpMapPoints is updated (map.tracked is read, never written).
+    int SearchByProjection(FrameView& F, const MapView& map, const float th) {
+        const int m = (int)map.bad.size(), nc = (int)F.mvKeysUn.size();
+        F.mvpMapPoints.resize(nc, -1);
+        Grid grid(mpCamera, F);
+        std::vector<int> rows;   // candidateMapPoints (:94-101), then the per-row skips (:111-117)
+        for (int i = 0; i < m; i++)
+            if (!map.bad[i] && map.in_view[i] && !map.tracked[i]) rows.push_back(i);
+        const int nr = (int)rows.size();
+        const bool bFactor = th != 1.0;
+        std::vector<float> uv(2 * (size_t)nr, 0.f), radius(nr, 4.0f);
+        std::vector<uint8_t> ok(nr, 1), claims(nr, 0), blocked(nc, 0);
+        DescMat d1(nr, 256);
+        for (int k = 0; k < nr; k++) {
+            const int id = rows[k];
+            float r = 4.0f;                                   // :127-133
+            if (map.viewcos[id] > 0.998) r = 2.5;
+            if (bFactor) r *= th;
+            radius[k] = r;
+            uv[2 * k] = map.proj[2 * id]; uv[2 * k + 1] = map.proj[2 * id + 1];
+            claims[k] = map.nobs[id] > 0;                     // :154-156 sees the slots this loop has filled
+            std::memcpy(d1.ptr(k), map.desc.ptr(id), sizeof(float) * 256);
+        }
+        for (int j = 0; j < nc; j++) blocked[j] = F.mvpMapPoints[j] >= 0 && map.nobs[F.mvpMapPoints[j]] > 0;
+        std::vector<int32_t> best(nr, -1);
+        int nmatches = 0;
+        run(grid, F.mDescriptors, d1, uv, radius, ok, &claims, &blocked, TH_HIGH, mfNNratio, -1.f, best, nmatches);
+        for (int k = 0; k < nr; k++)
+            if (best[k] >= 0) F.mvpMapPoints[best[k]] = rows[k];   // in loop order: later rows overwrite (:180)
+        return nmatches;
+    }
+
+    // matching/src/Matcher.cpp:1337-1411 (reached only from the uncalled Relocalization).  KF.mvpMapPoints:
+    // GetMapPointMatches() as ids; alreadyFound[id] = sAlreadyFound.count(pMP); Tcw = CurrentFrame.GetPose().
+    int SearchByProjection(FrameView& Cur, const FrameView& KF, const std::vector<uint8_t>& alreadyFound, const SE3f& Tcw,
+                           const MapPointsView& map, const float th, const float descDist) {
+        const int nk = (int)KF.mvpMapPoints.size(), nc = (int)Cur.mvKeysUn.size();
+        Cur.mvpMapPoints.resize(nc, -1);
+        Grid grid(mpCamera, Cur);
+        float Ow[3];
+        Tcw.center(Ow);
+        std::vector<float> uv(2 * (size_t)nk, 0.f), radius(nk, th);
+        std::vector<uint8_t> ok(nk, 0), claims(nk, 1), blocked(nc, 0);
+        DescMat d1(nk, 256);
+        for (int i = 0; i < nk; i++) {
+            const int id = KF.mvpMapPoints[i];
+            if (id < 0 || map.bad[id] || alreadyFound[id]) continue;
+            const float* pw = &map.pos[3 * (size_t)id];
+            float pc[3];
+            Tcw.apply(pw, pc);
+            project(pc, &uv[2 * i]);                          // no depth gate here (:1358-1362)
+            if (!ppg_grid_is_in_image(grid.g, uv[2 * i], uv[2 * i + 1])) continue;
+            const float PO[3] = {pw[0] - Ow[0], pw[1] - Ow[1], pw[2] - Ow[2]};
+            const float dist3D = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+            if (dist3D < map.min_dist[id] || dist3D > map.max_dist[id]) continue;
+            ok[i] = 1;
+            std::memcpy(d1.ptr(i), map.desc.ptr(id), sizeof(float) * 256);
+        }
+        for (int j = 0; j < nc; j++) blocked[j] = Cur.mvpMapPoints[j] >= 0;   // :1388-1389, and every accepted match fills its slot
+        std::vector<int32_t> best(nk, -1);
+        int nmatches = 0;
+        run(grid, Cur.mDescriptors, d1, uv, radius, ok, &claims, &blocked, descDist, 0.f, -1.f, best, nmatches);
+        for (int i = 0; i < nk; i++)
+            if (best[i] >= 0) Cur.mvpMapPoints[best[i]] = KF.mvpMapPoints[i];
+        return nmatches;
+    }
+
     // matching/src/Matcher.cpp:479-568.  Tcw = SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale()) (:483);
     // vpMatched holds map-point ids or -1.
     int SearchByProjection(const FrameView& KF, const SE3f& Tcw, const MapPointsView& map, const std::vector<int>& vpPoints,

@@ -72,6 +72,39 @@ static int projection_demo(Matcher& matcher, const CameraModel& cam, FrameView F
     for (size_t i = 0; i < fuse_pts.size(); i += 23) fuse_pts[i] = -1;
     const int n3 = matcher.Fuse(F[1], Tcw, map, fuse_pts, in_kf, 3.f, true, best_a);
     const int n4 = matcher.Fuse(F[1], Tcw, map, fuse_pts, in_kf, 4.f, false, best_b);
+    {   // the two overloads without a call site in the reference (Matcher.cpp:1337-1411, :89-189): they must run and
+        // respect their own rules (only empty slots are filled; no slot twice)
+        FrameView cur2 = F[1];
+        std::vector<uint8_t> found(map.size(), 0);
+        for (int i = 0; i < na; i += 7) found[i] = 1;
+        const int nd1 = matcher.SearchByProjection(cur2, F[0], found, Tcw, map, 15.f, 0.8f);
+        int filled = 0;
+        for (int j = 0; j < nb; j++) {
+            if (cur_before[j] >= 0 && cur2.mvpMapPoints[j] != cur_before[j]) { fprintf(stderr, "dead overload 1337 touched a taken slot\n"); return 3; }
+            if (cur_before[j] < 0 && cur2.mvpMapPoints[j] >= 0) { filled++; if (found[cur2.mvpMapPoints[j]]) return 3; }
+        }
+        if (nd1 != filled || nd1 < 10) { fprintf(stderr, "dead overload 1337: %d matches, %d slots filled\n", nd1, filled); return 3; }
+        MapView mv;
+        mv.desc = map.desc; mv.bad = map.bad; mv.nobs = map.nobs;
+        mv.in_view.assign(na, 1); mv.tracked.assign(na, 0); mv.viewcos.assign(na, 0.9f); mv.proj.assign(2 * (size_t)na, 0.f);
+        for (int i = 0; i < na; i++) {
+            float pc[3];
+            Tcw.apply(&map.pos[3 * (size_t)i], pc);
+            mv.proj[2 * i] = cam.K[0] * pc[0] / pc[2] + cam.K[2]; mv.proj[2 * i + 1] = cam.K[4] * pc[1] / pc[2] + cam.K[5];
+            mv.in_view[i] = i % 6 != 1; mv.tracked[i] = i % 10 == 2; if (i % 3 == 0) mv.viewcos[i] = 0.999f;
+        }
+        mv.edge_off.assign(na + 1, 0);
+        FrameView cur3 = F[1];
+        Matcher loose2(matcher.mCtx, &cam, 0.9f);
+        const int nd2 = loose2.SearchByProjection(cur3, mv, 3.f);
+        int changed = 0;
+        for (int j = 0; j < nb; j++) {
+            const int before = cur_before[j], after = cur3.mvpMapPoints[j];
+            if (before >= 0 && map.nobs[before] > 0 && after != before) { fprintf(stderr, "dead overload 89 replaced an observed point\n"); return 3; }
+            if (after != before) { changed++; if (map.bad[after] || !mv.in_view[after] || mv.tracked[after]) return 3; }
+        }
+        if (nd2 < changed || nd2 < 10) { fprintf(stderr, "dead overload 89: %d matches, %d slots changed\n", nd2, changed); return 3; }
+    }
     // ---- FeatureVector matchers: features filed by a 160-px position bucket, some nodes missing on either side ----
     auto file_features = [&](const FrameView& F, int drop_mod, int drop_rem) {
         std::vector<std::vector<unsigned>> bucket(64);

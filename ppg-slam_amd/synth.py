@@ -97,3 +97,26 @@ def frame_from_scene(scene: np.ndarray, height: int, width: int, t: int) -> np.n
 
 def make_frame(height: int, width: int, seed: int, t: int = 0, kind: str = "sparse") -> np.ndarray:
     return frame_from_scene(make_scene(height, width, seed, kind), height, width, t)
+
+
+def random_map_graph(rng, desc, pos, m, n_medges):
+    """A synthetic local map for Matcher::ExtendMapMatches: m map points sampled from a frame's key points (descriptor
+    and projection perturbed) and n_medges random map edges between them, as the flattened arrays of ppg_mapgraph."""
+    n = desc.shape[0]
+    src = rng.choice(n, size=m, replace=False)
+    mdesc = desc[src] + 0.15 * rng.normal(size=(m, 256)).astype(np.float32) / 16
+    mdesc = (mdesc / np.linalg.norm(mdesc, axis=1, keepdims=True)).astype(np.float32)
+    inc = [[] for _ in range(m)]
+    for eid in range(n_medges):
+        a, b = rng.choice(m, size=2, replace=False)
+        inc[a].append((eid, int(b)))
+        inc[b].append((eid, int(a)))
+    ne = sum(len(i) for i in inc)
+    other = np.array([o for i in inc for _, o in i], np.int32)
+    other[rng.random(ne) < 0.05] = -1
+    return dict(desc=mdesc, proj=(pos[src] + rng.uniform(-4, 4, (m, 2))).astype(np.float32),
+                viewcos=rng.uniform(0.99, 1.0, m).astype(np.float32), in_view=(rng.random(m) < 0.8).astype(np.uint8),
+                bad=(rng.random(m) < 0.05).astype(np.uint8), nobs=rng.integers(0, 3, m).astype(np.int32),
+                edge_off=np.cumsum([0] + [len(i) for i in inc]).astype(np.int32),
+                edge_id=np.array([e for i in inc for e, _ in i], np.int32), edge_other=other,
+                edge_ok=(rng.random(ne) < 0.9).astype(np.uint8))
