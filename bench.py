@@ -370,29 +370,39 @@ def main():
 
     # Fourth pass (fp32 runs only): the same step with the 3x3 convolutions in the fp16 hi/lo-split mode
     # (ppg_config.precision = 3), reported beside the number of record, never as it.
-    split = None
+    split, split_bf16 = None, None
     if args.precision == 0 and not args.no_split_pass:
         do_match[0] = True
-        ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=args.max_num, device_id=local_rank, precision=3))
-        run(0, PREROLL + 1)
-        barrier()
-        t2 = time.perf_counter()
-        ns = max(nb, min(args.steps, 40))
-        run(PREROLL + 1, ns)
-        barrier()
-        dt2 = time.perf_counter() - t2
-        if dist is not None:
-            tt = torch.tensor([dt2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt2 = float(tt.item())
-        split = {"value": round(B * ns * world / dt2, 1), "unit": "frames/s", "steps": ns, "dtype": "f16x3",
-                 "what": "the same step with ppg_config.precision = 3: the 3x3 convolutions (98 % of the FLOPs) on the fp16 "
-                         "MFMA with every operand scaled by a power of two and split into fp16 hi + lo, three products, fp32 "
-                         "accumulate (about 22 significant bits per operand); tensors within 4e-6 of the fp32 path, "
-                         "descriptors within 1e-4, key points equal up to ties within 4e-5 in score; integer outputs are "
-                         "not bit-exact against the CPU restatement, which only the fp32 mode is"}
-        ctx.close()
-        ctx = main_ctx
+
+        def split_pass(precision, dtype, what):
+            nonlocal ctx
+            ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=args.max_num, device_id=local_rank, precision=precision))
+            run(0, PREROLL + 1)
+            barrier()
+            t2 = time.perf_counter()
+            ns = max(nb, min(args.steps, 40))
+            run(PREROLL + 1, ns)
+            barrier()
+            dt2 = time.perf_counter() - t2
+            if dist is not None:
+                tt = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt2 = float(tt.item())
+            ctx.close()
+            ctx = main_ctx
+            return {"value": round(B * ns * world / dt2, 1), "unit": "frames/s", "steps": ns, "dtype": dtype, "what": what}
+
+        split = split_pass(3, "f16x3",
+                           "the same step with ppg_config.precision = 3: the 3x3 convolutions (98 % of the FLOPs) on the fp16 "
+                           "MFMA with every operand scaled by a power of two and split into fp16 hi + lo, three products, fp32 "
+                           "accumulate (about 22 significant bits per operand); tensors within 4e-6 of the fp32 path, "
+                           "descriptors within 1e-4, key points equal up to ties within 4e-5 in score; integer outputs are "
+                           "not bit-exact against the CPU restatement, which only the fp32 mode is")
+        split_bf16 = split_pass(1, "bf16x3",
+                                "the same step with ppg_config.precision = 1 (BASELINE config 3, 'bf16 conv / fp32 descriptors', in "
+                                "its split form): the convolutions on the bf16 MFMA with operands split into bf16 hi + lo, three "
+                                "products, fp32 accumulate; descriptors within 1e-3 of the fp32 path, key-point sets equal up "
+                                "to near-ties; not bit-exact on the integer outputs")
 
     if rank == 0:
         dom_ms, dom_launches = prof["conv1a"]
@@ -441,6 +451,7 @@ def main():
             "batch_sweep": sweep,
             "matchers_ms": matchers,
             "f16_split_mode": split,
+            "bf16_split_mode": split_bf16,
             "device_ms_note": f"from a second pass of {nb} steps with events around every kernel class (not the timed region)",
         }
         tr = os.path.join(ROOT, "profiles", "traffic.json")

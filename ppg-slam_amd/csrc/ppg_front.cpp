@@ -148,7 +148,8 @@ struct ppg_ctx {
     int tail_cap = 0, pair_cap = 0, edge_cap = 0;
     float* lt_geo = nullptr;
     int *lt_col_off = nullptr, *lt_col_cur = nullptr;
-    uint32_t *lt_col_k = nullptr, *lt_pairs = nullptr, *lt_kill = nullptr, *lt_pend = nullptr, *lt_cst = nullptr;
+    float* lt_col_ent = nullptr;
+    uint32_t *lt_pairs = nullptr, *lt_kill = nullptr, *lt_pend = nullptr, *lt_cst = nullptr;
     bool lines_on_host = false;           // PPG_LINES_HOST=1: every frame's tail on the host (the statement the device tail is checked against)
     std::vector<uint32_t> fb_ij;          // host tail: one frame's candidates, fetched only for the frames that need it
     std::vector<float> fb_sc;
@@ -879,7 +880,7 @@ static int create_impl(ppg_ctx* c) {
     DA(lt_geo, B * c->tail_cap * 3);
     DA(lt_col_off, B * (c->maxn + 1));
     DA(lt_col_cur, B * c->maxn);
-    DA(lt_col_k, B * c->tail_cap);
+    DA(lt_col_ent, B * c->tail_cap * 4);
     DA(lt_pairs, B * (size_t)c->pair_cap * 2);
     DA(lt_kill, B * c->tail_cap);
     DA(lt_pend, B * c->tail_cap);
@@ -1097,7 +1098,7 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
         Slot& sl = c->slot[c->cur];
         ppg::LineTailArgs t;
         t.kp_un = c->kp_un; t.counters = c->counters; t.row_off = c->row_cnt; t.cand_ij = c->cand_ij; t.cand_sc = c->cand_sc;
-        t.cand_cap = c->cand_cap; t.geo = c->lt_geo; t.col_off = c->lt_col_off; t.col_cur = c->lt_col_cur; t.col_k = c->lt_col_k;
+        t.cand_cap = c->cand_cap; t.geo = c->lt_geo; t.col_off = c->lt_col_off; t.col_cur = c->lt_col_cur; t.col_ent = c->lt_col_ent;
         t.pairs = c->lt_pairs; t.pair_cap = c->pair_cap; t.kill_t = c->lt_kill; t.pend_t = c->lt_pend; t.cst = c->lt_cst;
         t.tail_cap = c->tail_cap; t.edge_idx = sl.edge_idx; t.edge_score = sl.edge_score; t.conn_off = sl.conn_off;
         t.conn_idx = sl.conn_idx; t.coline_off = sl.coline_off; t.coline_pairs = sl.coline_pairs; t.edge_cap = c->edge_cap;
@@ -1264,10 +1265,11 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
                           float nnratio, int32_t* d_match, int* d_mcounts);
 
 static int enqueue_extract(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
+    static const int skip = getenv("PPG_DEBUG_SKIP") ? atoi(getenv("PPG_DEBUG_SKIP")) : 0;  // measurement aid only
     int rc = ppg_inference(c, imgs, n, on_device);
-    if (!rc) rc = ppg_detect_keypoints(c, n);
-    if (!rc) rc = ppg_detect_lines(c, n);
-    if (!rc) rc = ppg_gen_descriptors(c, n);
+    if (!rc && !(skip & 1)) rc = ppg_detect_keypoints(c, n);
+    if (!rc && !(skip & 2)) rc = ppg_detect_lines(c, n);
+    if (!rc && !(skip & 4)) rc = ppg_gen_descriptors(c, n);
     return rc;
 }
 
@@ -1933,7 +1935,15 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
         f.list_rad = c->mListRad.p; f.near_len = c->mNearLen.p;
         f.near_idx = c->mTopI.p; f.near_dist = c->mTopD.p; f.match12 = d_match; f.best = c->mBest.p; f.second = c->mSecond.p;
         f.n_matches = d_mcounts;
+        static const bool dbg = getenv("PPG_DEBUG_MATCH") != nullptr;   // measurement aid: rounds and rescans to stderr
+        if (dbg) { HIPCHK(c, hipMemsetAsync(c->mCount + 2, 0, 2 * sizeof(int), s)); f.stats = c->mCount + 2; }
         HIPCHK(c, ppg::launch_match_fused(f, s));
+        if (dbg) {
+            int st[2];
+            HIPCHK(c, hipMemcpyAsync(st, c->mCount + 2, sizeof(st), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            fprintf(stderr, "[ppg] claim pass: %d problems, %d rounds, %d whole-row rescans\n", batch, st[0], st[1]);
+        }
         return PPG_OK;
     }
     HIPCHK(c, ppg::launch_dist_matrix_batched(dA, nA, M, (size_t)M * 256, dB, nB, M, (size_t)M * 256, 256, c->mD.p, M,

@@ -136,7 +136,7 @@ struct LineTailArgs {
     float* geo;               // [B][tail_cap][3] work: length, direction seen from i, direction seen from j
     int* col_off;             // [B][max_num+1] work: candidates per second end point j, then their exclusive offsets
     int* col_cur;             // [B][max_num] work
-    uint32_t* col_k;          // [B][tail_cap] work: candidate indices grouped by j
+    float* col_ent;           // [B][tail_cap][4] work: candidates grouped by j: length, direction seen from j, index (bits), pad
     uint32_t* pairs;          // [B][pair_cap][2] work: (later candidate, earlier candidate | end point << 30 | code << 31)
     int pair_cap;
     uint32_t* kill_t;         // [B][tail_cap] work
@@ -219,6 +219,7 @@ struct FusedMatchArgs {
     int32_t* match12;                     // [batch][maxn]
     float* best; float* second;           // [batch][maxn] or both nullptr
     int* n_matches;                       // [batch]
+    int* stats = nullptr;                 // optional device ints: [0] += rounds of the claim pass, [1] += whole-row rescans
 };
 hipError_t launch_match_fused(const FusedMatchArgs& a, hipStream_t s);
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s);

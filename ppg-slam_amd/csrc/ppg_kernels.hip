@@ -1566,10 +1566,14 @@ __global__ __launch_bounds__(256) void line_col_fill_kernel(LineTailArgs a) {
     if (nc > a.tail_cap) return;
     const uint32_t* cij = a.cand_ij + (size_t)b * a.cand_cap;
     const int* col = a.col_off + (size_t)b * (a.max_num + 1);
+    const float* geo = a.geo + (size_t)b * a.tail_cap * 3;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < nc; k += gridDim.x * 256) {
         const int j = cij[k] & 0xFFFFu;
-        const int pos = atomicAdd(&a.col_cur[(size_t)b * a.max_num + j], 1);
-        a.col_k[(size_t)b * a.tail_cap + col[j] + pos] = (uint32_t)k;   // order inside a column is immaterial
+        const int pos = col[j] + atomicAdd(&a.col_cur[(size_t)b * a.max_num + j], 1);   // order inside a column is immaterial
+        // the list entry carries what a partner test needs (length, direction seen from j), so that walking a list is
+        // one contiguous read instead of a gather per entry
+        f32x4 e = {geo[3 * k], geo[3 * k + 2], __uint_as_float((uint32_t)k), 0.f};
+        *(f32x4*)(a.col_ent + ((size_t)b * a.tail_cap + pos) * 4) = e;
     }
 }
 
@@ -1597,49 +1601,88 @@ __device__ inline int line_interaction(float dn, float ln, float dy, float ly, f
     return ln <= ly ? 1 : 2;
 }
 
-// sixteen lanes per candidate c = (i, j): its partners are the candidates listed at i (second end point i: earlier
-// rows), the earlier candidates of its own row (first end point i), and the earlier candidates listed at j
+// Two lines interact only at a shared end point, so the pairs are enumerated point by point: one wave per point p
+// holds the lines incident at p (those listed at p as second end point, then p's own row) sixty-four at a time in
+// registers and tests every line against every earlier one (candidate order) by lane broadcast.  For a candidate
+// c = (i, j) that is exactly its partners at i (the lines listed at i and the earlier ones of its row) and at j
+// (the earlier lines listed at j).  Interacting pairs are gathered in LDS and written with one slot reservation
+// per flush: a reservation per pass would put a returning atomic into the innermost loop.
+constexpr int LI_BUF = 256;
 __global__ __launch_bounds__(256) void line_inter_kernel(LineTailArgs a) {
+    __shared__ uint32_t buf[4][LI_BUF][2];
     const int b = blockIdx.y;
     int* cnt = a.counters + b * 8;
     const int nc = cnt[2];
     if (nc > a.tail_cap) return;
-    const uint32_t* cij = a.cand_ij + (size_t)b * a.cand_cap;
+    const int n = cnt[3];
     const float* geo = a.geo + (size_t)b * a.tail_cap * 3;
     const int* col = a.col_off + (size_t)b * (a.max_num + 1);
-    const uint32_t* colk = a.col_k + (size_t)b * a.tail_cap;
+    const float* cole = a.col_ent + (size_t)b * a.tail_cap * 4;
     const int* rowoff = a.row_off + (size_t)b * (a.max_num + 1);
     uint32_t* cst = a.cst + (size_t)b * a.tail_cap;
     uint32_t* pairs = a.pairs + (size_t)b * a.pair_cap * 2;
-    const int gl = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t (*wb)[2] = buf[wave];
     bool risky = false, full = false;
-    for (int k = (blockIdx.x * 256 + threadIdx.x) >> 4; k < nc; k += gridDim.x * 16) {
-        const uint32_t ij = cij[k];
-        const int i = ij >> 16, j = ij & 0xFFFFu;
-        const float ln = geo[3 * k], dni = geo[3 * k + 1], dnj = geo[3 * k + 2];
-        const int a0 = col[i], nA = col[i + 1] - a0;
-        const int r0 = rowoff[i], nB = k - r0;
-        const int c0 = col[j], nC = col[j + 1] - c0;
-        const int total = nA + nB + nC;
-        for (int t = gl; t < total; t += 16) {
-            int y, ep;
-            float dy;
-            if (t < nA) { y = (int)colk[a0 + t]; ep = 0; dy = geo[3 * y + 2]; }
-            else if (t < nA + nB) { y = r0 + (t - nA); ep = 0; dy = geo[3 * y + 1]; }
-            else {
-                y = (int)colk[c0 + (t - nA - nB)];
-                if (y >= k) continue;   // a later row's line at j: not there yet when c arrives
-                ep = 1; dy = geo[3 * y + 2];
-            }
-            const int code = line_interaction(ep ? dnj : dni, ln, dy, geo[3 * y], a.dist_thresh, risky);
-            if (code == 0) continue;
-            const int slot = atomicAdd(&cnt[6], 1);
+    int nh = 0;   // pairs waiting in the wave's buffer (wave-uniform)
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cnt[6], nh);
+        base = __shfl(base, 0);
+        for (int q = lane; q < nh; q += 64) {
+            const int slot = base + q;
             if (slot >= a.pair_cap) { full = true; continue; }
-            pairs[2 * slot] = (uint32_t)k;
-            pairs[2 * slot + 1] = (uint32_t)y | ((uint32_t)ep << 30) | ((uint32_t)(code == 1) << 31);
-            if (code == 2) atomicOr(&cst[k], ep ? CS_HAS_RJ : CS_HAS_RI);
+            pairs[2 * slot] = wb[q][0];
+            pairs[2 * slot + 1] = wb[q][1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        nh = 0;
+    };
+    for (int p = blockIdx.x * 4 + wave; p < n; p += gridDim.x * 4) {
+        const int a0 = col[p], nA = col[p + 1] - a0;
+        const int r0 = rowoff[p], nR = (p + 1 < n ? rowoff[p + 1] : nc) - r0;
+        const int tot = nA + nR;
+        if (tot < 2) continue;
+        auto load = [&](int e, float& len, float& dir, int& k) {   // entry e of the point's list, its direction seen from p
+            if (e < nA) {
+                const f32x4 v = *(const f32x4*)(cole + (size_t)(a0 + e) * 4);
+                len = v[0]; dir = v[1]; k = (int)__float_as_uint(v[2]);
+            } else if (e < tot) {
+                k = r0 + (e - nA); len = geo[3 * k]; dir = geo[3 * k + 1];
+            } else { k = -1; len = 0.f; dir = 0.f; }
+        };
+        for (int cb = 0; cb < tot; cb += 64) {
+            float cl, cd; int ck;
+            load(cb + lane, cl, cd, ck);
+            const int ep = (cb + lane) < nA ? 1 : 0;
+            // earlier lines sit in the chunks up to the own one, except that the listed lines of a chunk are in no
+            // particular order: their chunks are all visited
+            const int y_end = cb + 64 < nA ? nA : min(cb + 64, tot);
+            for (int yb = 0; yb < y_end; yb += 64) {
+                float yl0, yd0; int yk0;
+                load(yb + lane, yl0, yd0, yk0);
+                const int m = min(64, tot - yb);
+                for (int sidx = 0; sidx < m; sidx++) {
+                    const float yl = __shfl(yl0, sidx), yd = __shfl(yd0, sidx);
+                    const int yk = __shfl(yk0, sidx);
+                    int code = 0;
+                    if (yk < ck) code = line_interaction(cd, cl, yd, yl, a.dist_thresh, risky);
+                    const unsigned long long hit = __ballot(code != 0);
+                    if (hit == 0ull) continue;
+                    if (code != 0) {
+                        const int q = nh + __popcll(hit & ((1ull << lane) - 1ull));
+                        wb[q][0] = (uint32_t)ck;
+                        wb[q][1] = (uint32_t)yk | ((uint32_t)ep << 30) | ((uint32_t)(code == 1) << 31);
+                        if (code == 2) atomicOr(&cst[ck], ep ? CS_HAS_RJ : CS_HAS_RI);
+                    }
+                    nh += __popcll(hit);
+                    if (nh > LI_BUF - 64) flush();
+                }
+            }
         }
     }
+    if (nh) flush();
     if (risky) atomicOr(&cnt[5], LT_GUARD);
     if (full) atomicOr(&cnt[5], LT_CAP);
 }
@@ -2531,6 +2574,7 @@ struct JacobiArgs {
     int32_t* match12;   // [batch][maxn]
     float* best; float* second;   // [batch][maxn] or nullptr
     int* n_matches;     // [batch]
+    int* stats;         // optional: [0] += rounds, [1] += rows that needed a whole-row scan (summed over rounds)
 };
 
 __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
@@ -2596,6 +2640,7 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
         }
         __syncthreads();
         const int nfb = fb_n;
+        if (a.stats && tid == 0) { atomicAdd(&a.stats[0], 1); atomicAdd(&a.stats[1], nfb); }
         for (int f = 0; f < nfb; f++) {   // rare; these rows all read the same claims, so their order is immaterial
             const int r = fb_rows[f];
             Best2 v = {1e6f, 1e6f, -1, -1};
@@ -2655,7 +2700,7 @@ hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
     j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
     j.nA = f.nA; j.nB = f.nB;
     j.near_idx = f.near_idx; j.near_dist = f.near_dist; j.near_len = f.near_len; j.th = f.th; j.ratio = f.ratio; j.match12 = f.match12;
-    j.best = f.best; j.second = f.second; j.n_matches = f.n_matches;
+    j.best = f.best; j.second = f.second; j.n_matches = f.n_matches; j.stats = f.stats;
     hipLaunchKernelGGL(match_jacobi_kernel, dim3(f.batch), dim3(1024), 0, s, j);
     return hipGetLastError();
 }
