@@ -201,7 +201,7 @@ struct ppg_ctx {
     DBuf<float> mNorm;
     DBuf<int32_t> mListCnt, mNearLen;
     DBuf<float> mListRad;
-    DBuf<uint16_t> mListCol;
+    DBuf<uint16_t> mListCol, mHalf;
     // device copy of the vocabulary last used with ppg_bow_transform*
     unsigned long long voc_serial = 0;
     float* voc_desc = nullptr;
@@ -755,7 +755,7 @@ void ppg_destroy(ppg_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
-                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p, c->mSkipOut.p, c->mRowClaims.p, c->xArena.p,
+                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mHalf.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p, c->mSkipOut.p, c->mRowClaims.p, c->xArena.p,
                   c->voc_desc, c->voc_child_off, c->voc_child_idx, c->voc_word, c->voc_weight};
     for (void* p : ms)
         if (p) (void)hipFree(p);
@@ -885,7 +885,7 @@ static int create_impl(ppg_ctx* c) {
     DA(lt_kill, B * c->tail_cap);
     DA(lt_pend, B * c->tail_cap);
     DA(lt_cst, B * c->tail_cap);
-    DA(mCount, 4);
+    DA(mCount, 16);
     HA(h_mcount, 4);
     for (Slot& sl : c->slot) {
 #define DS(ptr, n) do { rc = dalloc(c, &sl.ptr, (n)); if (rc) return rc; } while (0)
@@ -1468,6 +1468,7 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     if (!rc && fused) rc = grow(c, c->mNorm, (size_t)2 * std::max(nA, nB));
     if (!rc && fused) rc = grow(c, c->mListCnt, (size_t)std::max(nA, nB));
     if (!rc && fused) rc = grow(c, c->mListCol, (size_t)std::max(nA, nB) * 64);
+    if (!rc && fused) rc = grow(c, c->mHalf, (size_t)2 * std::max(nA, nB) * 256);
     if (!rc) rc = grow(c, c->mMatch, nA);
     if (!rc) rc = grow(c, c->mBest, nA);
     if (!rc) rc = grow(c, c->mSecond, nA);
@@ -1486,7 +1487,7 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
         ppg::FusedMatchArgs f;
         f.A = c->mA.p; f.B = c->mB.p; f.sA = 0; f.sB = 0; f.nA_dev = nullptr; f.nB_dev = nullptr; f.sn = 0; f.nA = nA; f.nB = nB;
         f.maxn = std::max(nA, nB); f.batch = 1; f.th = th; f.ratio = ratio;
-        f.norm_work = c->mNorm.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
+        f.norm_work = c->mNorm.p; f.half_work = c->mHalf.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
         f.list_rad = c->mListRad.p; f.near_len = c->mNearLen.p;
         f.near_idx = c->mTopI.p; f.near_dist = c->mTopD.p; f.match12 = c->mMatch.p; f.best = c->mBest.p; f.second = c->mSecond.p;
         f.n_matches = c->mCount;
@@ -1923,6 +1924,7 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
     if (!rc && fused) rc = grow(c, c->mNorm, (size_t)2 * M * batch);
     if (!rc && fused) rc = grow(c, c->mListCnt, (size_t)M * batch);
     if (!rc && fused) rc = grow(c, c->mListCol, (size_t)M * batch * 64);
+    if (!rc && fused) rc = grow(c, c->mHalf, (size_t)2 * M * batch * 256);
     if (rc) return rc;
     hipStream_t s = c->post;
     ProfScope ps(c, PPG_PROF_MATCH, c->post);
@@ -1931,18 +1933,21 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
         ppg::FusedMatchArgs f;
         f.A = dA; f.B = dB; f.sA = (size_t)M * 256; f.sB = (size_t)M * 256; f.nA_dev = nA; f.nB_dev = nB; f.sn = 8;
         f.maxn = M; f.batch = batch; f.th = 0.7f /* TH_LOW, Matcher.cpp:13 */; f.ratio = nnratio;
-        f.norm_work = c->mNorm.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
+        f.norm_work = c->mNorm.p; f.half_work = c->mHalf.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
         f.list_rad = c->mListRad.p; f.near_len = c->mNearLen.p;
         f.near_idx = c->mTopI.p; f.near_dist = c->mTopD.p; f.match12 = d_match; f.best = c->mBest.p; f.second = c->mSecond.p;
         f.n_matches = d_mcounts;
+        static const int mskip = getenv("PPG_DEBUG_MATCH_SKIP") ? atoi(getenv("PPG_DEBUG_MATCH_SKIP")) : 0;
+        f.debug_skip = mskip;
         static const bool dbg = getenv("PPG_DEBUG_MATCH") != nullptr;   // measurement aid: rounds and rescans to stderr
-        if (dbg) { HIPCHK(c, hipMemsetAsync(c->mCount + 2, 0, 2 * sizeof(int), s)); f.stats = c->mCount + 2; }
+        if (dbg) { HIPCHK(c, hipMemsetAsync(c->mCount + 2, 0, 8 * sizeof(int), s)); f.stats = c->mCount + 2; }
         HIPCHK(c, ppg::launch_match_fused(f, s));
         if (dbg) {
-            int st[2];
+            int st[8];
             HIPCHK(c, hipMemcpyAsync(st, c->mCount + 2, sizeof(st), hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
-            fprintf(stderr, "[ppg] claim pass: %d problems, %d rounds, %d whole-row rescans\n", batch, st[0], st[1]);
+            fprintf(stderr, "[ppg] claim pass: %d problems, %d rounds, %d whole-row rescans; slowest problem: %d rounds, %d rescans, "
+                            "%.1f us of which %.1f us in rescans (100 MHz clock)\n", batch, st[0], st[1], st[4], st[5], st[2] * 0.01, st[3] * 0.01);
         }
         return PPG_OK;
     }

@@ -211,6 +211,7 @@ struct FusedMatchArgs {
     int maxn, batch;
     float th, ratio;
     float* norm_work;                     // [2][batch][maxn] work
+    uint16_t* half_work;                  // [2][batch][maxn][256] work: the rows in fp16 (16-byte aligned)
     int* list_cnt;                        // [batch][maxn] work
     uint16_t* list_col;                   // [batch][maxn][64] work
     float* list_rad;                      // [batch][maxn] work
@@ -219,7 +220,9 @@ struct FusedMatchArgs {
     int32_t* match12;                     // [batch][maxn]
     float* best; float* second;           // [batch][maxn] or both nullptr
     int* n_matches;                       // [batch]
-    int* stats = nullptr;                 // optional device ints: [0] += rounds of the claim pass, [1] += whole-row rescans
+    int* stats = nullptr;                 // optional device ints: [0] += rounds of the claim pass, [1] += whole-row rescans,
+                                          // [2..5] the slowest problem: its time and its rescan time (100 MHz ticks), rounds, rescans
+    int debug_skip = 0;                   // measurement aid: 1 no claim pass, 2 no exact pass, 4 no prefilter (results are wrong)
 };
 hipError_t launch_match_fused(const FusedMatchArgs& a, hipStream_t s);
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s);

@@ -2301,12 +2301,15 @@ hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
 // Every distance the reference's loop can ask for is DescriptorDistance = one fused-multiply-add chain over the 256
 // components; evaluating it for all pairs is 2 x 256 VALU operations per pair on the issue port the convolutions'
 // MFMAs share.  Only the few nearest columns of a row can ever become its best or second-best match, so:
-//   row_norm_kernel        |row|^2 of every descriptor
-//   match_prefilter_kernel |a|^2 + |b|^2 - 2 a.b for all pairs on the fp32 MFMA (one v_mfma_f32_32x32x2 per 2048
-//                          products instead of 4096 VALU operations), kept in registers, never written: per row a
-//                          bound T on its 8th smallest value, and the columns within T + margin are listed.  The
-//                          margin covers the rounding of both evaluations (|approx - chain| <= 1.2e-4 for rows of
-//                          norm <= 1), so the list holds the 8 columns that are nearest by the exact chain.
+//   row_norm_kernel        |row|^2 of every descriptor and a copy of the row rounded to fp16
+//   match_prefilter_kernel |a|^2 + |b|^2 - 2 a.b for all pairs on the fp16 MFMA (fp32 accumulate), kept in registers,
+//                          never written: per row a bound T on its 16th smallest value, and the columns within
+//                          T + margin are listed.  The margin covers the rounding of the operands to fp16 and of
+//                          both evaluations (|approx - chain| <= 2.2e-3 for rows of norm <= 1; the values lie in
+//                          [0, 4], so that costs about one more listed column per row), which makes the list a
+//                          superset of the 16 columns that are nearest by the exact chain.  In fp16 the pass needs
+//                          1/16 of the matrix-core time of an fp32 MFMA; that time is what it takes from the
+//                          convolutions running beside it.
 //   match_exact_kernel     the exact chain for the listed columns only (about 10 per row), sorted: the same
 //                          eight-nearest lists match_topk_kernel makes from the full matrix
 //   match_jacobi_kernel    the sequential claim pass as a fixed point: given a guess of every row's match, each row
@@ -2315,15 +2318,19 @@ hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
 //                          round t; in practice a handful of rounds).
 // =====================================================================================
 constexpr int PF_ROWS = 32, PF_MAXCOLS = 1024, PF_LIST = 64;
+constexpr int PF_WAVES = 8, PF_THREADS = 64 * PF_WAVES, PF_Q = PF_MAXCOLS / 32 / PF_WAVES;   // column tiles per wave
 constexpr int PF_K = 16;        // T bounds the PF_K-th smallest value of a row
 constexpr int PF_NEAR = 32;     // length of the sorted nearest lists handed to the claim pass
-// |approx - chain| <= PF_EPS for rows of norm <= 1 (three roundings of 256-term sums); the listing threshold is
-// T + PF_MARGIN with PF_MARGIN >= 2 * PF_EPS, so every column whose exact squared distance is <= T + PF_MARGIN - PF_EPS
-// is listed: up to that radius the sorted list is the true nearest-neighbour order with nothing missing.
-constexpr float PF_MARGIN = 3.0e-4f, PF_EPS = 1.2e-4f;
+// |approx - chain| <= PF_EPS for rows of norm <= 1.  Rounding a and b to fp16 (relative 2^-11 per component, absolute
+// 2^-25 below the normal range) moves a.b by at most (2^-10 + 2^-22) |a||b| + 2^-20 <= 9.8e-4, twice that in the
+// squared distance; the fp16 products are exact in fp32, the fp32 accumulation, the two norms and the chain's own
+// rounding add less than 2e-4.  The listing threshold is T + PF_MARGIN with PF_MARGIN >= 2 * PF_EPS, so every column
+// whose exact squared distance is <= T + PF_MARGIN - PF_EPS is listed: up to that radius the sorted list is the
+// true nearest-neighbour order with nothing missing.
+constexpr float PF_MARGIN = 4.5e-3f, PF_EPS = 2.2e-3f;
 
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ X, const int* n_dev, int sn, int maxn, size_t sX,
-                                                       float* __restrict__ out, int n_host) {
+                                                       float* __restrict__ out, uint16_t* __restrict__ half_out, int n_host) {
     const int b = blockIdx.y;
     const int n = n_dev ? min(maxn, n_dev[b * sn]) : n_host;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -2332,6 +2339,9 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
     float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     s = wave_sum(s);
     if (lane == 0) out[(size_t)b * maxn + row] = s;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};   // round to nearest even
+    *(f16x4*)(half_out + ((size_t)b * maxn + row) * 256 + lane * 4) = h;
 }
 
 // order-preserving map of float bit patterns to unsigned
@@ -2349,14 +2359,15 @@ struct PrefilterArgs {
     const int* nA_dev; const int* nB_dev; int sn;   // row counts on the device, or nullptr: nA / nB below
     int nA, nB;
     const float* normA; const float* normB;  // [batch][maxn]
+    const uint16_t* halfA; const uint16_t* halfB;   // [batch][maxn][256] the rows in fp16
     int maxn;
     int* list_cnt;                         // [batch][maxn]
     uint16_t* list_col;                    // [batch][maxn][PF_LIST]
     float* list_rad;                       // [batch][maxn] squared radius up to which the list is complete
 };
 
-__global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[PF_ROWS][260];
+__global__ __launch_bounds__(PF_THREADS) void match_prefilter_kernel(PrefilterArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[PF_ROWS][264];   // fp16 rows, padded against bank conflicts
     __shared__ float nas[PF_ROWS];
     __shared__ uint32_t gmin[PF_ROWS][32];
     __shared__ float thr[PF_ROWS];
@@ -2365,52 +2376,62 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
     const int b = blockIdx.y, r0 = blockIdx.x * PF_ROWS;
     const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
     if (r0 >= nA) return;
-    const float* A = a.A + b * a.sA;
-    const float* B = a.B + b * a.sB;
+    const uint16_t* A = a.halfA + (size_t)b * a.maxn * 256;
+    const uint16_t* B = a.halfB + (size_t)b * a.maxn * 256;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    for (int idx = tid; idx < PF_ROWS * 64; idx += 256) {
-        const int r = idx >> 6, c4 = idx & 63;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r0 + r < nA) v = *(const f32x4*)(A + (size_t)(r0 + r) * 256 + c4 * 4);
-        *(f32x4*)&As[r][c4 * 4] = v;
+    for (int idx = tid; idx < PF_ROWS * 32; idx += PF_THREADS) {
+        const int r = idx >> 5, c8 = idx & 31;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < nA) v = *(const u32x4*)(A + (size_t)(r0 + r) * 256 + c8 * 8);
+        *(u32x4*)&As[r][c8 * 8] = v;
     }
     if (tid < PF_ROWS) {
         nas[tid] = r0 + tid < nA ? a.normA[(size_t)b * a.maxn + r0 + tid] : 0.f;
         lcount[tid] = 0;
     }
-    for (int idx = tid; idx < PF_ROWS * 32; idx += 256) gmin[idx >> 5][idx & 31] = 0xFFFFFFFFu;
+    for (int idx = tid; idx < PF_ROWS * 32; idx += PF_THREADS) gmin[idx >> 5][idx & 31] = 0xFFFFFFFFu;
     __syncthreads();
     const int ntiles = (nB + 31) / 32;
-    f32x16 acc[8];
+    f32x16 acc[PF_Q];
 #pragma unroll
-    for (int q = 0; q < 8; q++)
+    for (int q = 0; q < PF_Q; q++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-    // lane (li, lh) supplies, for the e-th MFMA of step t, component 8t + 4*lh + e of its row (A) / column (B)
-    const float* brow[8];
-    bool bval[8];
+    // The order of the 256 products is free here, so lane (li, lh) walks its own half of the row / column: step u
+    // (0..15) of v_mfma_f32_32x32x16_f16 takes components 128*lh + 8*u .. +7 from it, sixteen bytes, the half row
+    // being two whole 128-byte lines.  One column tile's sixteen loads are in flight while the previous tile is
+    // multiplied.
+    const uint16_t* brow[PF_Q];
+    bool bval[PF_Q];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int col = (wave + 4 * q) * 32 + li;
+    for (int q = 0; q < PF_Q; q++) {
+        const int col = (wave + PF_WAVES * q) * 32 + li;
         bval[q] = col < nB;
-        brow[q] = B + (size_t)(bval[q] ? col : 0) * 256 + 4 * lh;
+        brow[q] = B + (size_t)(bval[q] ? col : 0) * 256 + 128 * lh;   // a column past the end reads row 0; its sums are discarded
     }
-    for (int t = 0; t < 32; t++) {
-        const f32x4 av = *(const f32x4*)&As[li][8 * t + 4 * lh];
+    const uint16_t* arow = &As[li][128 * lh];
+    u32x4 bb[2][16];
+    auto load_tile = [&](int q, u32x4 (&dst)[16]) {
+        if (wave + PF_WAVES * q >= ntiles) return;   // uniform per wave
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (wave + 4 * q >= ntiles) continue;   // uniform per wave
-            f32x4 bv = *(const f32x4*)(brow[q] + 8 * t);
-            if (!bval[q]) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 16; u++) dst[u] = *(const u32x4*)(brow[q] + 8 * u);
+    };
+    load_tile(0, bb[0]);
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[q], 0, 0, 0);
+    for (int q = 0; q < PF_Q; q++) {
+        if (q + 1 < PF_Q) load_tile(q + 1, bb[(q + 1) & 1]);
+        if (wave + PF_WAVES * q >= ntiles) continue;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const u32x4 av = *(const u32x4*)(arow + 8 * u);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bb[q & 1][u]), acc[q], 0, 0, 0);
         }
     }
     // approx = |a|^2 + |b|^2 - 2 a.b; lane holds column li of each of its tiles and rows (r&3) + 8*(r>>2) + 4*lh
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        if (wave + 4 * q >= ntiles) continue;
-        const int col = (wave + 4 * q) * 32 + li;
+    for (int q = 0; q < PF_Q; q++) {
+        if (wave + PF_WAVES * q >= ntiles) continue;
+        const int col = (wave + PF_WAVES * q) * 32 + li;
         const float nb = bval[q] ? a.normB[(size_t)b * a.maxn + col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -2423,13 +2444,13 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
     for (int r = 0; r < 16; r++) {
         float m = 3.0e38f;
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-            if (wave + 4 * q < ntiles) m = fminf(m, acc[q][r]);
+        for (int q = 0; q < PF_Q; q++)
+            if (wave + PF_WAVES * q < ntiles) m = fminf(m, acc[q][r]);
         atomicMin(&gmin[(r & 3) + 8 * (r >> 2) + 4 * lh][li], fkey(m));
     }
     __syncthreads();
-    for (int rr = 0; rr < 8; rr++) {
-        const int row = wave * 8 + rr;
+    for (int rr = 0; rr < PF_ROWS / PF_WAVES; rr++) {
+        const int row = wave * (PF_ROWS / PF_WAVES) + rr;
         const uint32_t mine = gmin[row][li];
         int rank = 0;
 #pragma unroll
@@ -2444,9 +2465,9 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        if (wave + 4 * q >= ntiles || !bval[q]) continue;
-        const int col = (wave + 4 * q) * 32 + li;
+    for (int q = 0; q < PF_Q; q++) {
+        if (wave + PF_WAVES * q >= ntiles || !bval[q]) continue;
+        const int col = (wave + PF_WAVES * q) * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -2457,7 +2478,7 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < PF_ROWS * PF_LIST; idx += 256) {
+    for (int idx = tid; idx < PF_ROWS * PF_LIST; idx += PF_THREADS) {
         const int r = idx / PF_LIST, sidx = idx % PF_LIST;
         if (r0 + r < nA && sidx < min(lcount[r], PF_LIST))
             a.list_col[((size_t)b * a.maxn + r0 + r) * PF_LIST + sidx] = llist[r][sidx];
@@ -2468,15 +2489,21 @@ __global__ __launch_bounds__(256) void match_prefilter_kernel(PrefilterArgs a) {
     }
 }
 
+// The chain takes a whole 128-byte line of each operand at a time: a lane that walks its row sixteen bytes per load
+// comes back to every line eight times, and with a row per lane the L1 has dropped it by then.
 __device__ inline float chain_distance2(const float* __restrict__ x, const float* __restrict__ y) {
     float acc = 0.f;
-    for (int d = 0; d < 256; d += 4) {
-        const f32x4 u = *(const f32x4*)(x + d), v = *(const f32x4*)(y + d);
+    for (int d = 0; d < 256; d += 32) {
+        f32x4 u[8], v[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float t = u[q] - v[q];
-            acc = fmaf(t, t, acc);
-        }
+        for (int q = 0; q < 8; q++) { u[q] = *(const f32x4*)(x + d + 4 * q); v[q] = *(const f32x4*)(y + d + 4 * q); }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float t = u[q][e] - v[q][e];
+                acc = fmaf(t, t, acc);
+            }
     }
     return acc;
 }
@@ -2577,13 +2604,16 @@ struct JacobiArgs {
     int* stats;         // optional: [0] += rounds, [1] += rows that needed a whole-row scan (summed over rounds)
 };
 
+constexpr int JB_FB = 8;   // rows of one whole-row scan pass
+
 __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
     __shared__ uint32_t claim[PF_MAXCOLS];     // smallest row whose current guess is this column
     __shared__ int32_t guess[PF_MAXCOLS];
     __shared__ int fb_rows[PF_MAXCOLS];
     __shared__ int fb_n, fb_changed;
-    __shared__ float rb[16], rs[16];
-    __shared__ int rp[16];
+    __shared__ float rb[JB_FB][16], rs[JB_FB][16];
+    __shared__ int rp[JB_FB][16];
+    __shared__ __attribute__((aligned(16))) float xs[JB_FB][256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
     const float* A = a.A + b * a.sA;
@@ -2609,6 +2639,9 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
     int mine = -1;
     float mbest = 1e6f, msecond = 1e6f;
     __syncthreads();
+    const long long t_begin = a.stats ? (long long)wall_clock64() : 0;
+    long long t_fb = 0;
+    int n_round = 0, n_fb = 0;
     for (int round = 0; round <= nA; round++) {
         for (int j = tid; j < nB; j += 1024) claim[j] = 0xFFFFFFFFu;
         if (tid == 0) { fb_n = 0; fb_changed = 0; }
@@ -2640,32 +2673,73 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
         }
         __syncthreads();
         const int nfb = fb_n;
-        if (a.stats && tid == 0) { atomicAdd(&a.stats[0], 1); atomicAdd(&a.stats[1], nfb); }
-        for (int f = 0; f < nfb; f++) {   // rare; these rows all read the same claims, so their order is immaterial
-            const int r = fb_rows[f];
-            Best2 v = {1e6f, 1e6f, -1, -1};
-            for (int col = tid; col < nB; col += 1024) {
-                if (claim[col] < (uint32_t)r) continue;
-                const float d = chain_distance(A + (size_t)r * 256, B + (size_t)col * 256);
-                if (d < v.b) { v.b2 = v.b; v.b = d; v.pos = col; v.idx = col; }
-                else if (d < v.b2) v.b2 = d;
+        if (a.stats && tid == 0) { atomicAdd(&a.stats[0], 1); atomicAdd(&a.stats[1], nfb); n_round++; n_fb += nfb; }
+        const long long t_f0 = a.stats ? (long long)wall_clock64() : 0;
+        // rare; these rows all read the same claims, so their order is immaterial.  Up to JB_FB of them share one
+        // pass over the columns: a thread reads its column once and runs one chain per row against the rows in LDS.
+        for (int f0 = 0; f0 < nfb; f0 += JB_FB) {
+            const int nb = min(JB_FB, nfb - f0);
+            for (int idx = tid; idx < nb * 64; idx += 1024) {
+                const int rr = idx >> 6, c4 = (idx & 63) * 4;
+                *(f32x4*)&xs[rr][c4] = *(const f32x4*)(A + (size_t)fb_rows[f0 + rr] * 256 + c4);
             }
-            v = best2_wave(v);
-            if (lane == 0) { rb[wave] = v.b; rs[wave] = v.b2; rp[wave] = v.pos; }
             __syncthreads();
-            if (tid == r) {
-                Best2 q = {rb[0], rs[0], rp[0], rp[0]};
-                for (int w = 1; w < 16; w++) q = best2_merge(q, Best2{rb[w], rs[w], rp[w], rp[w]});
-                const int m = (q.pos >= 0 && q.b <= a.th && q.b < q.b2 * a.ratio) ? q.pos : -1;
-                if (m != mine) fb_changed = 1;
-                mine = m; mbest = q.b; msecond = q.b2;
+            float acc[JB_FB];
+#pragma unroll
+            for (int rr = 0; rr < JB_FB; rr++) acc[rr] = 0.f;
+            const int col = tid;
+            if (col < nB) {
+                const float* y = B + (size_t)col * 256;
+                for (int d = 0; d < 256; d += 16) {
+                    f32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = *(const f32x4*)(y + d + 4 * q);
+#pragma unroll
+                    for (int rr = 0; rr < JB_FB; rr++) {
+                        if (rr >= nb) continue;   // uniform
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const f32x4 u = *(const f32x4*)&xs[rr][d + 4 * q];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float t = u[e] - v[q][e];
+                                acc[rr] = fmaf(t, t, acc[rr]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < JB_FB; rr++) {
+                if (rr >= nb) continue;
+                const int r = fb_rows[f0 + rr];
+                Best2 v = {1e6f, 1e6f, -1, -1};
+                if (col < nB && !(claim[col] < (uint32_t)r)) { v.b = sqrtf(acc[rr]); v.pos = col; v.idx = col; }
+                v = best2_wave(v);
+                if (lane == 0) { rb[rr][wave] = v.b; rs[rr][wave] = v.b2; rp[rr][wave] = v.pos; }
+            }
+            __syncthreads();
+            if (fallback) {
+                for (int rr = 0; rr < nb; rr++) {
+                    if (fb_rows[f0 + rr] != i) continue;
+                    Best2 q = {rb[rr][0], rs[rr][0], rp[rr][0], rp[rr][0]};
+                    for (int w = 1; w < 16; w++) q = best2_merge(q, Best2{rb[rr][w], rs[rr][w], rp[rr][w], rp[rr][w]});
+                    const int m = (q.pos >= 0 && q.b <= a.th && q.b < q.b2 * a.ratio) ? q.pos : -1;
+                    if (m != mine) fb_changed = 1;
+                    mine = m; mbest = q.b; msecond = q.b2;
+                }
             }
             __syncthreads();
         }
         (void)fallback;
+        if (a.stats) t_fb += (long long)wall_clock64() - t_f0;
         if (i < nA) guess[i] = mine;
         const int fbc = fb_changed;   // read before the barrier: thread 0 clears it at the top of the next round
         if (__syncthreads_count(changed | fbc) == 0) break;
+    }
+    if (a.stats && tid == 0) {   // the slowest problem of the batch: [2] its time, [3] of which rescans, [4] rounds, [5] rescans
+        const int t_all = (int)((long long)wall_clock64() - t_begin);
+        if (atomicMax(&a.stats[2], t_all) < t_all) { a.stats[3] = (int)t_fb; a.stats[4] = n_round; a.stats[5] = n_fb; }
     }
     if (i < nA) {
         a.match12[(size_t)b * a.maxn + i] = mine;
@@ -2674,11 +2748,11 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
     int cnt = (i < nA && mine >= 0) ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     __syncthreads();
-    if (lane == 0) rp[wave] = cnt;
+    if (lane == 0) rp[0][wave] = cnt;
     __syncthreads();
     if (tid == 0) {
         int tot = 0;
-        for (int w = 0; w < 16; w++) tot += rp[w];
+        for (int w = 0; w < 16; w++) tot += rp[0][w];
         a.n_matches[b] = tot;
     }
 }
@@ -2690,12 +2764,15 @@ hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
     p.nA = f.nA; p.nB = f.nB;
     if (!f.nA_dev && (f.nA > f.maxn || f.nB > f.maxn || f.nA < 0 || f.nB < 0)) return hipErrorInvalidValue;
     p.normA = f.norm_work; p.normB = f.norm_work + (size_t)f.batch * f.maxn; p.maxn = f.maxn;
+    p.halfA = f.half_work; p.halfB = f.half_work + (size_t)f.batch * f.maxn * 256;
     p.list_cnt = f.list_cnt; p.list_col = f.list_col; p.list_rad = f.list_rad;
     dim3 gn((f.maxn + 3) / 4, f.batch);
-    hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.A, f.nA_dev, f.sn, f.maxn, f.sA, f.norm_work, f.nA);
-    hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.maxn, f.sB, f.norm_work + (size_t)f.batch * f.maxn, f.nB);
-    hipLaunchKernelGGL(match_prefilter_kernel, dim3((f.maxn + PF_ROWS - 1) / PF_ROWS, f.batch), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(match_exact_kernel, gn, dim3(256), 0, s, p, f.near_idx, f.near_dist, f.near_len);
+    hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.A, f.nA_dev, f.sn, f.maxn, f.sA, f.norm_work, f.half_work, f.nA);
+    hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.maxn, f.sB, f.norm_work + (size_t)f.batch * f.maxn,
+                       f.half_work + (size_t)f.batch * f.maxn * 256, f.nB);
+    if (!(f.debug_skip & 4)) hipLaunchKernelGGL(match_prefilter_kernel, dim3((f.maxn + PF_ROWS - 1) / PF_ROWS, f.batch), dim3(PF_THREADS), 0, s, p);
+    if (!(f.debug_skip & 2)) hipLaunchKernelGGL(match_exact_kernel, gn, dim3(256), 0, s, p, f.near_idx, f.near_dist, f.near_len);
+    if (f.debug_skip & 1) return hipGetLastError();
     JacobiArgs j;
     j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
     j.nA = f.nA; j.nB = f.nB;
