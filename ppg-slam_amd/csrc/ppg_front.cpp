@@ -90,6 +90,11 @@ struct Slot {
     float* h_edge_score = nullptr;
     int32_t *h_conn_off = nullptr, *h_coline_off = nullptr;
     hipEvent_t cnn_done = nullptr;
+    hipEvent_t match_done = nullptr;   // the batch's match against the previous one and its copies (match stream)
+    // everything the host reads of a batch lies in one device block and one pinned block of the same layout, so a
+    // full batch comes back in a single copy (with one frame per call thirteen small copies were a tenth of the call)
+    uint8_t *d_res = nullptr, *h_res = nullptr;
+    size_t res_bytes = 0;
     // pinned host mirrors
     int* h_counters = nullptr;
     int32_t* h_kp_xy = nullptr;
@@ -129,6 +134,10 @@ struct ppg_ctx {
     hipStream_t post = nullptr;         // everything after the CNN, matching, copies to the host
     hipStream_t copy_stream = nullptr;  // late copies of an already finished slot
     hipStream_t up_stream = nullptr;    // image uploads: the copy of batch k+1 runs beside the CNN of batch k
+    // all-pairs match of resident descriptors: beside the post-processing of the next batch instead of in front of it
+    // (with one frame per call the claim pass alone is a quarter of the post stream's time)
+    hipStream_t match_stream = nullptr;
+    hipEvent_t ev_desc_ready = nullptr;
     std::vector<void*> dev_allocs, host_allocs;
     // weights
     DevConv c1b, c2a, c2b, c3a, c3b, c4a, c4b, pa, pb, da, db, h0, h1, h2;
@@ -630,6 +639,25 @@ void undistort_rectify_maps(const ppg_config& c, std::vector<float>& mx, std::ve
     }
 }
 
+// Tile grid of a launch.  A launch of the big tile (256 pixels x 64 couts per work-group) that would put fewer than
+// kQuarterBelow work-groups on the chip (256 CUs take three each) goes out in quarter-size work-groups instead: with
+// one or two frames per call the deep layers are 20 to 300 big tiles, and the launch lasts as long as one of them.
+constexpr int kQuarterBelow = 600;
+void conv_tiling(ppg::ConvArgs& a, const DevConv& dc, int mode, bool fused) {
+    const int H = a.H, W = a.W;
+    a.mw = fused ? 32 : pick_tile(dc, H, W, mode);
+    a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
+    a.quarter = 0;
+    static const bool never = getenv("PPG_NO_QUARTER_TILES") != nullptr;
+    if (never || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
+    if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;
+    a.quarter = 1;
+    // pooling pairs the two rows of an 8 x 16 tile's pixel tiles; otherwise the shape with the least padded area
+    const long a32 = (long)((H + 3) / 4 * 4) * ((W + 31) / 32 * 32), a16 = (long)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16);
+    a.mw = (mode == ppg::CONV_POOL2 || a16 < a32) ? 16 : 32;
+    a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 128 / a.mw - 1) / (128 / a.mw);
+}
+
 ppg::ConvGroup conv_group(const DevConv& dc, float* out, int mode, int relu, int nblk0) {
     ppg::ConvGroup g;
     g.out = out; g.bias = dc.bias; g.alpha = dc.alpha; g.beta = dc.beta;
@@ -643,8 +671,8 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
     if (fused_img) { a.img = fused_img; a.w1a = c->c1a_w; a.b1a = c->c1a_b; }
     a.in = in; a.wpk = dc.w; a.prec = dc.lowp ? c->cfg.precision : 0; a.sat = c->slot[c->cur].sat;
     a.B = n; a.H = H; a.W = W; a.Cin = dc.cin;
-    a.mw = fused_img ? 32 : pick_tile(dc, H, W, mode);
-    a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw); a.nblk = dc.nblk;
+    a.nblk = dc.nblk;
+    conv_tiling(a, dc, mode, fused_img != nullptr);
     a.ngroups = 1;
     a.g[0] = conv_group(dc, out, mode, relu, 0);
     const int cls = fused_img ? PPG_PROF_CONV1A : (dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER);
@@ -660,9 +688,8 @@ int run_heads(ppg_ctx* c, int n, int H, int W) {
     ppg::ConvArgs a;
     a.in = c->feat; a.wpk = c->heads_w; a.prec = c->pa.lowp ? c->cfg.precision : 0; a.sat = c->slot[c->cur].sat;
     a.B = n; a.H = H; a.W = W; a.Cin = c->pa.cin;
-    a.mw = pick_tile(c->pa, H, W, ppg::CONV_PLAIN);
-    a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
     a.nblk = c->pa.nblk + c->da.nblk + c->h0.nblk;
+    conv_tiling(a, c->pa, ppg::CONV_PLAIN, false);
     a.ngroups = 3;
     a.g[0] = conv_group(c->pa, c->pa_o, ppg::CONV_PLAIN, 1, 0);
     a.g[1] = conv_group(c->da, c->da_o, ppg::CONV_PLAIN, 1, c->pa.nblk);
@@ -751,6 +778,7 @@ void ppg_destroy(ppg_ctx* c) {
         if (l.stream) (void)hipStreamSynchronize(l.stream);
     if (c->post) (void)hipStreamSynchronize(c->post);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    if (c->match_stream) (void)hipStreamSynchronize(c->match_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
@@ -763,12 +791,15 @@ void ppg_destroy(ppg_ctx* c) {
     for (Slot& sl : c->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.cnn_done) (void)hipEventDestroy(sl.cnn_done);
+        if (sl.match_done) (void)hipEventDestroy(sl.match_done);
     }
+    if (c->ev_desc_ready) (void)hipEventDestroy(c->ev_desc_ready);
     for (Lane& l : c->lane)
         if (l.stream) (void)hipStreamDestroy(l.stream);
     if (c->post) (void)hipStreamDestroy(c->post);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->match_stream) (void)hipStreamDestroy(c->match_stream);
     delete c;
 }
 
@@ -808,6 +839,8 @@ static int create_impl(ppg_ctx* c) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     // same priority as the CNN: at a lower one the short upload kernel would starve behind every pending convolution work-group
     HIPCHK(c, hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, prio_hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->match_stream, hipStreamNonBlocking, prio_lo));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_desc_ready, hipEventDisableTiming));
     {
         const char* u = getenv("PPG_UNFUSED_CONV1A");
         c->unfused_conv1a = u && atoi(u) != 0;
@@ -890,13 +923,35 @@ static int create_impl(ppg_ctx* c) {
     for (Slot& sl : c->slot) {
 #define DS(ptr, n) do { rc = dalloc(c, &sl.ptr, (n)); if (rc) return rc; } while (0)
 #define HS(ptr, n) do { rc = halloc(c, &sl.ptr, (n)); if (rc) return rc; } while (0)
-        DS(counters, B * 8);
+        {
+            size_t off = 0;
+            auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+            const size_t E = c->edge_cap, M1 = c->maxn + 1;
+            const size_t o_cnt = take(sizeof(int) * 8 * B), o_xy = take(sizeof(int32_t) * 2 * B * c->maxn),
+                         o_sc = take(sizeof(float) * B * c->maxn), o_un = take(sizeof(float) * 2 * B * c->maxn),
+                         o_out = take((size_t)B * c->maxn), o_desc = take(sizeof(float) * 256 * B * c->maxn),
+                         o_ei = take(sizeof(uint32_t) * 2 * E * B), o_es = take(sizeof(float) * E * B),
+                         o_co = take(sizeof(int32_t) * M1 * B), o_ci = take(sizeof(uint32_t) * 2 * E * B),
+                         o_lo = take(sizeof(int32_t) * M1 * B), o_lp = take(sizeof(uint32_t) * 2 * E * B);
+            sl.res_bytes = off;
+            DS(d_res, off);
+            HS(h_res, off);
+#define RES(dev, host, T, o) do { sl.dev = (T*)(sl.d_res + (o)); sl.host = (T*)(sl.h_res + (o)); } while (0)
+            RES(counters, h_counters, int, o_cnt);
+            RES(kp_xy, h_kp_xy, int32_t, o_xy);
+            RES(kp_score, h_kp_score, float, o_sc);
+            RES(kp_un, h_kp_un, float, o_un);
+            RES(kp_out, h_kp_out, uint8_t, o_out);
+            RES(desc, h_desc, float, o_desc);
+            RES(edge_idx, h_edge_idx, uint32_t, o_ei);
+            RES(edge_score, h_edge_score, float, o_es);
+            RES(conn_off, h_conn_off, int32_t, o_co);
+            RES(conn_idx, h_conn_idx, uint32_t, o_ci);
+            RES(coline_off, h_coline_off, int32_t, o_lo);
+            RES(coline_pairs, h_coline_pairs, uint32_t, o_lp);
+#undef RES
+        }
         DS(sat, 1);
-        DS(kp_xy, B * c->maxn * 2);
-        DS(kp_score, B * c->maxn);
-        DS(kp_un, B * c->maxn * 2);
-        DS(kp_out, B * c->maxn);
-        DS(desc, B * c->maxn * 256);
         DS(cand_ij, B * c->cand_cap);
         DS(cand_sc, B * c->cand_cap * 2);
         DS(d_match, B * c->maxn);
@@ -904,26 +959,8 @@ static int create_impl(ppg_ctx* c) {
         DS(junc, B * hw * 65);
         DS(hs2, B * HW * 4);
         DS(descmap, B * hw * 256);
-        DS(edge_idx, B * c->edge_cap * 2);
-        DS(edge_score, B * c->edge_cap);
-        DS(conn_off, B * (c->maxn + 1));
-        DS(conn_idx, B * c->edge_cap * 2);
-        DS(coline_off, B * (c->maxn + 1));
-        DS(coline_pairs, B * c->edge_cap * 2);
-        HS(h_counters, B * 8);
         HS(h_sat, 1);
         sl.h_sat[0] = 0;
-        HS(h_kp_xy, B * c->maxn * 2);
-        HS(h_kp_score, B * c->maxn);
-        HS(h_kp_un, B * c->maxn * 2);
-        HS(h_kp_out, B * c->maxn);
-        HS(h_desc, B * c->maxn * 256);
-        HS(h_edge_idx, B * c->edge_cap * 2);
-        HS(h_edge_score, B * c->edge_cap);
-        HS(h_conn_off, B * (c->maxn + 1));
-        HS(h_conn_idx, B * c->edge_cap * 2);
-        HS(h_coline_off, B * (c->maxn + 1));
-        HS(h_coline_pairs, B * c->edge_cap * 2);
         HS(h_match, B * c->maxn);
         HS(h_mcounts, B);
         HS(h_img, B * HW);
@@ -933,6 +970,7 @@ static int create_impl(ppg_ctx* c) {
         HIPCHK(c, hipMemset(sl.counters, 0, sizeof(int) * 8 * B));
         HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&sl.cnn_done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.match_done, hipEventDisableTiming));
         sl.frames.resize(B);
         sl.nkp.assign(B, 0);
     }
@@ -1127,25 +1165,31 @@ static int enqueue_d2h(ppg_ctx* c, int si, int n) {
     Slot& sl = c->slot[si];
     const int M = c->maxn;
     hipStream_t s = c->post;
-    HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.counters, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, s));
     if (c->cfg.precision == 3) HIPCHK(c, hipMemcpyAsync(sl.h_sat, sl.sat, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(sl.h_kp_xy, sl.kp_xy, sizeof(int32_t) * 2 * M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(sl.h_kp_score, sl.kp_score, sizeof(float) * M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(sl.h_kp_un, sl.kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(sl.h_kp_out, sl.kp_out, (size_t)M * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(sl.h_desc, sl.desc, sizeof(float) * 256 * M * n, hipMemcpyDeviceToHost, s));
-    if (!c->lines_on_host) {
-        const size_t E = c->edge_cap;
-        HIPCHK(c, hipMemcpyAsync(sl.h_edge_idx, sl.edge_idx, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_edge_score, sl.edge_score, sizeof(float) * E * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_conn_off, sl.conn_off, sizeof(int32_t) * (M + 1) * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_conn_idx, sl.conn_idx, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_coline_off, sl.coline_off, sizeof(int32_t) * (M + 1) * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_coline_pairs, sl.coline_pairs, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
+    if (n == c->B && !c->lines_on_host) {
+        HIPCHK(c, hipMemcpyAsync(sl.h_res, sl.d_res, sl.res_bytes, hipMemcpyDeviceToHost, s));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.counters, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_kp_xy, sl.kp_xy, sizeof(int32_t) * 2 * M * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_kp_score, sl.kp_score, sizeof(float) * M * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_kp_un, sl.kp_un, sizeof(float) * 2 * M * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_kp_out, sl.kp_out, (size_t)M * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_desc, sl.desc, sizeof(float) * 256 * M * n, hipMemcpyDeviceToHost, s));
+        if (!c->lines_on_host) {
+            const size_t E = c->edge_cap;
+            HIPCHK(c, hipMemcpyAsync(sl.h_edge_idx, sl.edge_idx, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_edge_score, sl.edge_score, sizeof(float) * E * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_conn_off, sl.conn_off, sizeof(int32_t) * (M + 1) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_conn_idx, sl.conn_idx, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_coline_off, sl.coline_off, sizeof(int32_t) * (M + 1) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_coline_pairs, sl.coline_pairs, sizeof(uint32_t) * 2 * E * n, hipMemcpyDeviceToHost, s));
+        }
     }
     if (sl.matched) {
-        HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+        hipStream_t ms = c->match_stream;
+        HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, ms));
+        HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, ms));
+        HIPCHK(c, hipEventRecord(sl.match_done, ms));
     }
     HIPCHK(c, hipEventRecord(sl.done, s));
     return PPG_OK;
@@ -1160,6 +1204,7 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
     hipStream_t s = c->copy_stream;
     const double t_sync0 = now_ms();
     HIPCHK(c, hipEventSynchronize(sl.done));
+    if (sl.matched) HIPCHK(c, hipEventSynchronize(sl.match_done));
     if (c->prof) { c->prof_ms[PPG_PROF_HOST_WAIT] += now_ms() - t_sync0; c->prof_launches[PPG_PROF_HOST_WAIT] += 1; }
     if (c->cfg.precision == 3 && sl.h_sat[0])
         return fail(c, PPG_ERANGE, "an activation left the range of the fp16 split (|x| > 2047): use precision 0 or 1");
@@ -1422,6 +1467,7 @@ int ppg_dist_matrix(ppg_ctx* c, const float* A, int nA, const float* B, int nB, 
     if (!rc) rc = grow(c, c->mD, (size_t)nA * nB);
     if (rc) return rc;
     hipStream_t s = c->post;
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     HIPCHK(c, hipMemcpyAsync(c->mA.p, A, sizeof(float) * nA * dim, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->mB.p, B, sizeof(float) * nB * dim, hipMemcpyHostToDevice, s));
     HIPCHK(c, ppg::launch_dist_matrix(c->mA.p, nA, c->mB.p, nB, dim, c->mD.p, nB, s));
@@ -1441,6 +1487,7 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     if (nA == 0) return PPG_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     hipStream_t s = c->post;
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     const bool csr = cand_off != nullptr;
     const size_t nd = csr ? (size_t)cand_off[nA] : (size_t)nA * nB;
     if (csr) {
@@ -1693,6 +1740,7 @@ int ppg_dist_lists(ppg_ctx* c, const float* A, int nA, const float* B, int nB, i
         if (cand_idx[k] < 0 || cand_idx[k] >= nB) return fail(c, PPG_EINVAL, "cand_idx[%zu] out of range", k);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     hipStream_t s = c->post;
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     int rc = grow(c, c->mA, (size_t)nA * dim);
     if (!rc) rc = grow(c, c->mB, (size_t)nB * dim);
     if (!rc) rc = grow(c, c->mD, nd);
@@ -1730,6 +1778,7 @@ int ppg_distinctive_descriptors(ppg_ctx* c, const float* desc, const int32_t* se
     const size_t nd = idx.size();
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     hipStream_t s = c->post;
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     int rc = grow(c, c->mA, (size_t)rows * dim);
     if (!rc) rc = grow(c, c->mD, nd);
     if (!rc) rc = grow(c, c->mOff, (size_t)rows + 1);
@@ -1840,6 +1889,7 @@ int ppg_match_projected(ppg_ctx* c, const ppg_proj_args* a, int32_t* best_idx, f
     if (nd == 0) return PPG_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     hipStream_t s = c->post;
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     int rc = grow(c, c->mA, (size_t)n1 * dim);
     if (!rc) rc = grow(c, c->mB, (size_t)n2 * dim);
     if (!rc) rc = grow(c, c->mD, nd);
@@ -1926,8 +1976,11 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
     if (!rc && fused) rc = grow(c, c->mListCol, (size_t)M * batch * 64);
     if (!rc && fused) rc = grow(c, c->mHalf, (size_t)2 * M * batch * 256);
     if (rc) return rc;
-    hipStream_t s = c->post;
-    ProfScope ps(c, PPG_PROF_MATCH, c->post);
+    // the descriptors come from the post stream; the matcher's work arrays belong to the match stream
+    hipStream_t s = c->match_stream;
+    HIPCHK(c, hipEventRecord(c->ev_desc_ready, c->post));
+    HIPCHK(c, hipStreamWaitEvent(s, c->ev_desc_ready, 0));
+    ProfScope ps(c, PPG_PROF_MATCH, s);
     if (fused) {
         // descriptors out of desc_sample_kernel have norm 1 (or are all zero), which the prefilter's margin assumes
         ppg::FusedMatchArgs f;
@@ -1974,9 +2027,9 @@ int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, in
     int rc = match_resident(c, c->desc + (size_t)fa * M * 256, c->counters + fa * 8 + 3, c->desc + (size_t)fb * M * 256,
                             c->counters + fb * 8 + 3, 1, nnratio, sl.d_match, sl.d_mcounts);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M, hipMemcpyDeviceToHost, c->post));
-    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int), hipMemcpyDeviceToHost, c->post));
-    HIPCHK(c, hipStreamSynchronize(c->post));
+    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M, hipMemcpyDeviceToHost, c->match_stream));
+    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int), hipMemcpyDeviceToHost, c->match_stream));
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));
     if (c->prof) prof_resolve(c);
     memcpy(m12, sl.h_match, sizeof(int32_t) * sl.nkp[fa]);
     if (n_matches) *n_matches = sl.h_mcounts[0];
@@ -1994,9 +2047,9 @@ int ppg_match_prev_batch(ppg_ctx* c, int n, float nnratio, int32_t* m12, int* n_
     const int M = c->maxn;
     int rc = match_resident(c, c->desc_prev, c->counters_prev + 3, c->desc, c->counters + 3, n, nnratio, sl.d_match, sl.d_mcounts);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, c->post));
-    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, c->post));
-    HIPCHK(c, hipStreamSynchronize(c->post));
+    HIPCHK(c, hipMemcpyAsync(sl.h_match, sl.d_match, sizeof(int32_t) * M * n, hipMemcpyDeviceToHost, c->match_stream));
+    HIPCHK(c, hipMemcpyAsync(sl.h_mcounts, sl.d_mcounts, sizeof(int) * n, hipMemcpyDeviceToHost, c->match_stream));
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));
     if (c->prof) prof_resolve(c);
     for (int b = 0; b < n; b++) {
         memcpy(m12 + (size_t)b * M, sl.h_match + (size_t)b * M, sizeof(int32_t) * prev.nkp[b]);
@@ -2200,6 +2253,7 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
     for (const Part& p : parts)
         if (p.bytes) memcpy(c->xHost.data() + p.off, p.src, p.bytes);
     hipStream_t s = c->post;
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     uint8_t* base = c->xArena.p;
     HIPCHK(c, hipMemcpyAsync(base, c->xHost.data(), oWdist, hipMemcpyHostToDevice, s));
     auto dp = [&](size_t i) { return base + parts[i].off; };
@@ -2280,6 +2334,7 @@ int bow_run(ppg_ctx* c, const ppg_vocab* v, const float* d_desc, size_t stride_b
     if (!rc) rc = grow(c, c->bWeight, (size_t)n * batch);
     if (rc) return rc;
     hipStream_t s = c->post;
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     ppg::BowArgs a;
     a.desc = d_desc; a.stride_batch = stride_batch; a.n = n; a.n_dev = n_dev; a.sn = sn;
     a.node_desc = c->voc_desc; a.child_off = c->voc_child_off; a.child_idx = c->voc_child_idx; a.word_id = c->voc_word;

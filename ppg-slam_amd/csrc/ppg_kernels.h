@@ -33,6 +33,7 @@ struct ConvArgs {
     int B, H, W, Cin;
     int tiles_x, tiles_y, nblk;  // nblk = cout blocks of all groups together
     int mw = 32;         // tile shape: 32 -> 8 x 32 pixels, 16 -> 16 x 16 pixels (3x3, 64-cout blocks only)
+    int quarter = 0;     // 1: quarter-size work-groups (fp32 3x3, 64-cout blocks): 4 x 32 (mw 32) or 8 x 16 (mw 16) pixels x 32 couts
     int ngroups = 1;
     ConvGroup g[3];
 };

@@ -19,12 +19,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Epilogue of the convolution kernels: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store.
 // acc[m][n] is the 32 x 32 result of pixel tile m and cout tile n in the MFMA D layout (lane = pixel l&31,
 // register r = cout (r&3) + 8*(r>>2) + 4*(l>>5)).
-template <int NT, int MW>
-__device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc)[2][NT], int wave, int li, int lh, int x0,
-                                           int y0, int b, int nb) {
+template <int NT, int MW, int MT = 2, bool HALF = false>
+__device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc)[MT][NT], int wave, int li, int lh, int x0,
+                                           int y0, int b, int nb_launch) {
     constexpr int NB = 32 * NT;
-    auto prow = [&](int m, int i) { return MW == 32 ? 2 * wave + m : 4 * wave + 2 * m + (i >> 4); };
+    auto prow = [&](int m, int i) { return MW == 32 ? MT * wave + m : 2 * MT * wave + 2 * m + (i >> 4); };
     auto pcol = [&](int i) { return MW == 32 ? i : (i & 15); };
+    // HALF: the launch counts 32-cout halves of the 64-cout blocks the layers are described in
+    const int nb = HALF ? nb_launch >> 1 : nb_launch;
     // A launch may serve up to three layers that read the same input (cout blocks [nblk0, next nblk0) each).
     // The lane owns one pixel of each pixel tile and, per cout tile, four runs of four consecutive couts
     // (registers 4j..4j+3 = couts 8j + 4*(l>>5) + 0..3): one 16-byte store per run.
@@ -32,7 +34,7 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
     if (a.ngroups > 1 && nb >= a.g[1].nblk0) gi = 1;
     if (a.ngroups > 2 && nb >= a.g[2].nblk0) gi = 2;
     const ConvGroup G = a.g[gi];
-    const int cb = (nb - G.nblk0) * NB;  // first cout of this block inside its layer (packed order)
+    const int cb = HALF ? (nb - G.nblk0) * 64 + (nb_launch & 1) * 32 : (nb - G.nblk0) * NB;  // first cout of this block inside its layer (packed order)
     const bool bn = G.alpha != nullptr;
     const bool vec = (G.Cout & 3) == 0;  // rows of the output are 16-byte aligned
     const int Cps = G.Cout >> 2;
@@ -54,19 +56,22 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
             f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
             if (bn) { al = *(const f32x4*)(G.alpha + co); be = *(const f32x4*)(G.beta + co); }
             if (G.mode == CONV_POOL2) {
-                if (MW != 32) continue;  // pooled layers always use the 8 x 32 tile
-                // rows 2*wave, 2*wave+1 are the two pixel tiles; the column neighbour is the next lane
-                const int y = y0 + 2 * wave, x = x0 + li;
+                // pooled layers use the 8 x 32 tile with two pixel tiles per wave (rows 2*wave, 2*wave+1 are the two
+                // tiles) or the 8 x 16 tile with one (the tile is two rows of 16: the row neighbour is lane ^ 16);
+                // the column neighbour is the next lane
+                if (!((MW == 32 && MT == 2) || (MW == 16 && MT == 1))) continue;
+                const int y = y0 + 2 * wave, x = x0 + pcol(li);
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float t = fmaxf(acc[0][n][4 * j + e], acc[1][n][4 * j + e]);
+                    const float t = MT == 2 ? fmaxf(acc[0][n][4 * j + e], acc[MT - 1][n][4 * j + e])
+                                            : fmaxf(acc[0][n][4 * j + e], __shfl_xor(acc[0][n][4 * j + e], 16));
                     const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));  // lane ^ 1
                     float r = fmaxf(t, o) + bias[e];
                     if (G.relu) r = fmaxf(r, 0.f);
                     v[e] = r;
                 }
-                if ((li & 1) == 0 && y + 1 < a.H && x + 1 < a.W) {
+                if ((li & 1) == 0 && (MT == 2 || li < 16) && y + 1 < a.H && x + 1 < a.W) {
                     float* dst = G.out + ((size_t)(b * (a.H / 2) + (y >> 1)) * (a.W / 2) + (x >> 1)) * G.Cout + co;
                     if (vec) *(f32x4*)dst = v;
                     else
@@ -75,7 +80,7 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
                 }
             } else {
 #pragma unroll
-                for (int m = 0; m < 2; m++) {
+                for (int m = 0; m < MT; m++) {
                     const int y = y0 + prow(m, li), x = x0 + pcol(li);
                     if (y >= a.H || x >= a.W) continue;
                     f32x4 v;
@@ -130,9 +135,14 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
 // Two tile shapes (MW = width of one 32-pixel M tile): MW = 32 -> 8 rows x 32 columns per work-group (an M
 // tile is one row segment), MW = 16 -> 16 x 16 (an M tile is 2 rows x 16 columns), which wastes less of
 // feature maps whose width is a multiple of 16 but not of 32 (e.g. 80 columns at 640/8).
-template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32>
+// MT = pixel tiles per wave.  MT = 1 halves the tile (4 x 32 or 8 x 16 pixels); with HALF the work-group also takes
+// only 32 of the 64 couts of a packed weight block (NT = 1): a quarter of the work per work-group, for launches that
+// would otherwise leave most of the chip idle (one frame per call: 20 to 300 big tiles on 256 CUs).  The chain of
+// every output is the same in all shapes.
+template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32, int MT = 2, bool HALF = false>
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
-    constexpr int TW = MW, TH = 256 / MW;
+    static_assert(!HALF || NT == 1, "HALF takes one 32-cout tile out of a 64-cout block");
+    constexpr int TW = MW, TH = 128 * MT / MW;
     constexpr int PAD = KS / 2;
     constexpr int IH = TH + KS - 1, IW = TW + KS - 1, IN_PIX = IH * IW;
     constexpr int PSTR = KC + 4;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     const int x0 = tx * TW, y0 = ty * TH;
     const int nchunks = a.Cin / KC;
     // pixel (row, column) inside the tile of A-operand lane li / accumulator row index i of M tile m
-    auto prow = [&](int m, int i) { return MW == 32 ? 2 * wave + m : 4 * wave + 2 * m + (i >> 4); };
+    auto prow = [&](int m, int i) { return MW == 32 ? MT * wave + m : 2 * MT * wave + 2 * m + (i >> 4); };
     auto pcol = [&](int i) { return MW == 32 ? i : (i & 15); };
 
     // Byte offset of each fetch slot inside the image (FUSE1A: float offset inside the patch).  Padding pixels
@@ -193,8 +203,17 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     // image b of the input and the packed weights of cout block nb, as buffers
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.in + (FUSE1A ? 0 : (size_t)b * a.H * a.W * a.Cin)), 0, FUSE1A ? 0 : a.H * a.W * a.Cin * 4, 0x00020000);
+    // HALF: the weights are packed for 64-cout blocks, [group][tap][cin half][64 couts][4]; this work-group's 32 couts
+    // are every other run of 32 x 16 bytes
+    constexpr int SRC_W = HALF ? 2 * W_FLOATS : W_FLOATS;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.wpk + (size_t)nb * nchunks * W_FLOATS), 0, nchunks * W_FLOATS * 4, 0x00020000);
+        (void*)(a.wpk + (size_t)(HALF ? nb >> 1 : nb) * nchunks * SRC_W), 0, nchunks * SRC_W * 4, 0x00020000);
+    int wofs[W_PER_T];
+#pragma unroll
+    for (int k = 0; k < W_PER_T; k++) {
+        const int it = tid + 256 * k;
+        wofs[k] = HALF ? (((it >> 5) * 64 + (nb & 1) * 32 + (it & 31)) * 16) : it * 16;
+    }
     if (FUSE1A) {
         // patch pixel (py, px) = image pixel (y0 - 2 + py, x0 - 2 + px); u8 -> f32 by a true division
         // (feature/src/PPGExtractor.cpp:151), zero outside the image (conv1a's own zero padding)
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         // slots past the chunk read the next chunk's weights (or zeros past the last one) into padding
 #pragma unroll
         for (int k = 0; k < W_PER_T; k++)
-            vw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + 256 * k) * 16, c * W_FLOATS * 4, 0));
+            vw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wofs[k], c * SRC_W * 4, 0));
         if (!FUSE1A) {
 #pragma unroll
             for (int k = 0; k < IN_PER_T; k++)
@@ -254,9 +273,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         for (int k = 0; k < W_PER_T; k++) *(f32x4*)(ws + (tid + 256 * k) * 4) = vw[k];
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int n = 0; n < NT; n++)
 #pragma unroll
@@ -274,9 +293,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int tap = 0; tap < TAPS; tap++) {
                 const int ky = tap / KS, kx = tap % KS;
-                f32x4 av[2], bv[NT];
+                f32x4 av[MT], bv[NT];
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                for (int m = 0; m < MT; m++)
                     av[m] = *(const f32x4*)(ins + ((prow(m, li) + ky) * IW + (pcol(li) + kx)) * PSTR + g * 8 + lh * 4);
 #pragma unroll
                 for (int n = 0; n < NT; n++)
@@ -284,7 +303,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int s = 0; s < 4; s++)
 #pragma unroll
-                    for (int m = 0; m < 2; m++)
+                    for (int m = 0; m < MT; m++)
 #pragma unroll
                         for (int n = 0; n < NT; n++)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[n][s], av[m][s], acc[m][n], 0, 0, 0);
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    conv_store<NT, MW>(a, acc, wave, li, lh, x0, y0, b, nb);
+    conv_store<NT, MW, MT, HALF>(a, acc, wave, li, lh, x0, y0, b, nb);
 }
 
 // =====================================================================================
@@ -549,6 +568,15 @@ int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
 
 hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
+    if (a.quarter) {
+        // quarter-size work-groups: fp32 3x3 layers with 64-cout blocks only; tiles_x / tiles_y count 4 x 32 or 8 x 16 tiles
+        if (ks != 3 || nt != 2 || a.img || a.prec != 0 || a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
+        if ((long)a.H * a.W * a.Cin * 4 > 0x7fffffffL) return hipErrorInvalidValue;
+        grid.y = 2 * a.nblk;
+        if (a.mw == 16) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8, false, 16, 1, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8, false, 32, 1, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
     // one image of the input is addressed as a buffer with 32-bit byte offsets
     if ((long)a.H * a.W * a.Cin * 4 > 0x7fffffffL) return hipErrorInvalidValue;
