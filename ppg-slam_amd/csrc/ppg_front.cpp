@@ -1214,6 +1214,12 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
             return fail(c, PPG_ECAP, "frame %d: work list overflow (resid %d kept %d cand %d)", b, cnt[0], cnt[1], cnt[2]);
     }
     if (c->prof) prof_resolve(c);
+    static const bool dbg_counters = getenv("PPG_DEBUG_COUNTERS") != nullptr;   // measurement aid: work-list sizes of frame 0
+    if (dbg_counters) {
+        const int* k = sl.h_counters;
+        fprintf(stderr, "[ppg] frame 0: %d residual pixels (%d rounds), %d kept, %d line candidates, %d key points, %d edges, %d pairs (%d rounds)\n",
+                k[0], k[7] & 255, k[1], k[2], k[3], k[4], k[6], k[7] >> 8);
+    }
     for (int b = 0; b < n; b++) sl.nkp[b] = sl.h_counters[b * 8 + 3];
     const double t_tail0 = now_ms();
     const int M1 = M + 1;

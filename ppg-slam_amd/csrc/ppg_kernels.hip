@@ -883,16 +883,32 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(NmsArgs a) {
             if (st[p] != 1) continue;
             const int py = p / a.W, px = p % a.W;
             const float sp = sc[p];
+            // The 80 state bytes of the window are fetched without a branch between them, so they are all in flight
+            // together (a scan that stops at the first kept pixel pays one memory latency per pixel looked at, and
+            // this kernel is one work-group per frame); only the undecided neighbours then need their score.
+            // (Candidates keep NR pixels from the border, so the whole window lies inside the image.)
             bool sup = false, blocked = false;
-            for (int dy = -NR; dy <= NR && !sup; dy++) {
-                const int qy = py + dy;
-                if (qy < 0 || qy >= a.H) continue;
-                for (int dx = -NR; dx <= NR; dx++) {
-                    const int qx = px + dx;
-                    if (qx < 0 || qx >= a.W || (dy | dx) == 0) continue;
-                    const uint8_t sq = st[qy * a.W + qx];
-                    if (sq == 2) { sup = true; break; }
-                    if (sq == 1 && beats(sc[qy * a.W + qx], dy, dx, sp)) blocked = true;
+            unsigned long long und0 = 0ull;   // undecided neighbours, window positions 0..63
+            unsigned und1 = 0u;               // positions 64..80
+            constexpr int NW = 2 * NR + 1;
+            const uint8_t* w0 = st + (py - NR) * a.W + (px - NR);
+            uint8_t sq[NW * NW];
+#pragma unroll
+            for (int t = 0; t < NW * NW; t++) sq[t] = w0[(t / NW) * a.W + (t % NW)];
+#pragma unroll
+            for (int t = 0; t < NW * NW; t++) {
+                if (t == NW * NR + NR) continue;
+                sup |= sq[t] == 2;
+                if (t < 64) und0 |= (unsigned long long)(sq[t] == 1) << t;
+                else und1 |= (unsigned)(sq[t] == 1) << (t - 64);
+            }
+            if (!sup) {
+                while (und0 | und1) {
+                    int t;
+                    if (und0) { t = __ffsll((long long)und0) - 1; und0 &= und0 - 1; }
+                    else { t = 64 + __ffs((int)und1) - 1; und1 &= und1 - 1; }
+                    const int dy = t / (2 * NR + 1) - NR, dx = t % (2 * NR + 1) - NR;
+                    if (beats(sc[(py + dy) * a.W + px + dx], dy, dx, sp)) { blocked = true; break; }
                 }
             }
             if (sup) st[p] = 3;
@@ -903,7 +919,7 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(NmsArgs a) {
             } else remaining++;
         }
         // barrier + work-group-wide visibility of the state bytes written above
-        if (__syncthreads_count(remaining) == 0) break;
+        if (__syncthreads_count(remaining) == 0) { if (threadIdx.x == 0) cnt[7] = round + 1; break; }
     }
 }
 
@@ -1799,7 +1815,7 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
             cst[k] = s;
             open += !(s & CS_ACC_KNOWN);
         }
-        if (__syncthreads_count(open) == 0) break;
+        if (__syncthreads_count(open) == 0) { if (tid == 0) cnt[7] |= (round + 1) << 8; break; }
     }
     // the last round's second-end-point kills of candidates settled in that round
     for (int p = tid; p < np; p += 1024) {
