@@ -1298,10 +1298,132 @@ __global__ __launch_bounds__(256) void refine_kernel(HeatArgs a) {
     }
 }
 
+// The same for tiles of at most 256 pixels that all have the full size (image sides multiples of refine_sz): one wave
+// per tile, four pixels per lane, no work-group barrier.  The ordered list of valid values exists only as (lane, slot)
+// positions — a lane's pixels are consecutive in row-major order, so its slice of the list starts at the wave prefix sum
+// of the valid counts —, the probe of the unsorted list is one lane lookup, and the k-th largest value comes from a
+// bit-by-bit bisection of the bit patterns with wave ballots.
+__global__ __launch_bounds__(256) void refine_wave_kernel(HeatArgs a) {
+    __shared__ float s_vals[4][256], s_sorted[4][256];   // only for the sequential fallback
+    const int S = a.refine_sz, area = S * S;
+    const int gxn = a.W / S, gyn = a.H / S;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long tile = (long)blockIdx.x * 4 + wave;
+    if (tile >= (long)gxn * gyn * a.B) return;
+    const int tj = (int)(tile % gxn), ti = (int)((tile / gxn) % gyn), b = (int)(tile / ((long)gxn * gyn));
+    const int h0 = ti * S, w0 = tj * S;
+    const float* src = a.prob + (size_t)b * a.H * a.W;
+    float* dst = a.refined + (size_t)b * a.H * a.W;
+    float v[4];
+    size_t o[4];
+    bool ok[4], in[4];
+    int cnt = 0;
+    bool big = false;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int p = 4 * lane + e;
+        in[e] = p < area;
+        o[e] = (size_t)(h0 + (in[e] ? p / S : 0)) * a.W + w0 + (in[e] ? p % S : 0);
+        v[e] = in[e] ? src[o[e]] : 0.f;
+        ok[e] = in[e] && v[e] > a.valid_thresh;
+        big |= in[e] && v[e] > 1.0f;
+        cnt += ok[e];
+    }
+    int inc = cnt;   // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    const int off = inc - cnt;
+    const int n = __shfl(inc, 63);
+    const bool any_big = __ballot(big) != 0ull;
+    const int valCount = (int)(a.valid_ratio * (float)n);
+    int action = 2;
+    if (valCount < 1) action = 0;
+    else if ((double)n >= (double)area * 0.9) {
+        // element (size_t)(n * 0.9) of the unsorted list
+        const int idx = (int)(size_t)((double)n * 0.9);
+        float mine = 0.f;
+        int r = idx - off;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (ok[e]) { if (r == 0) mine = v[e]; r--; }
+        const unsigned long long holder = __ballot(idx >= off && idx < off + cnt);
+        const float probe = __shfl(mine, __ffsll((long long)holder) - 1);
+        if ((double)probe > 0.1) action = 1;
+    }
+    float ave = 0.f;
+    if (action == 2 && a.valid_thresh >= 0x1p-20f && !any_big) {
+        // every value is a multiple of 2^-43 in (2^-20, 1]: sums of up to 256 of them are exact in double in any order
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) u[e] = ok[e] ? __float_as_uint(v[e]) : 0u;
+        uint32_t T = 0u;   // largest T with at least valCount keys >= T: the valCount-th largest key
+        for (int bit = 30; bit >= 0; bit--) {
+            const uint32_t cand = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) c += __popcll(__ballot(u[e] >= cand));
+            if (c >= valCount) T = cand;
+        }
+        double part = 0.0;
+        int above = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (u[e] > T) { part += (double)v[e]; above++; }
+        part = wave_sum_d(part);
+        for (int d = 32; d > 0; d >>= 1) above += __shfl_xor(above, d);
+        const double acc = part + (double)(valCount - above) * (double)__uint_as_float(T);
+        ave = (float)(acc / (double)(float)valCount);
+    } else if (action == 2) {
+        // sequential statement: rank by counting, then the additions in sorted order by one lane
+        float* vals = s_vals[wave];
+        float* sorted = s_sorted[wave];
+        int r = off;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (ok[e]) vals[r++] = v[e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int k = lane; k < n; k += 64) {
+            const float x = vals[k];
+            int rank = 0;
+            for (int j = 0; j < n; j++) {
+                const float y = vals[j];
+                rank += (y > x) || (y == x && j < k);
+            }
+            sorted[rank] = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double acc = 0.0;
+        if (lane == 0)
+            for (int k = 0; k < valCount; k++) acc += (double)sorted[k];
+        acc = __shfl(acc, 0);
+        ave = (float)(acc / (double)(float)valCount);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (!in[e]) continue;
+        float r = v[e];
+        if (action == 1) r = 0.f;
+        else if (action == 2) {
+            if (v[e] > a.valid_thresh) {
+                const float ns = v[e] / ave;
+                r = (double)ns > 1.0 ? 1.0f : ns;
+            } else r = 0.f;
+        }
+        dst[o[e]] = r;
+    }
+}
+
 hipError_t launch_refine(const HeatArgs& a, hipStream_t s) {
     const int S = a.refine_sz;
     if (S < 1 || (2 * S - 1) * (2 * S - 1) > RF_MAXPIX) return hipErrorInvalidValue;
     const int tiles = (a.W / S) * (a.H / S) * a.B;
+    if (S * S <= 256 && a.W % S == 0 && a.H % S == 0) {
+        hipLaunchKernelGGL(refine_wave_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(refine_kernel, dim3(tiles), dim3(256), 0, s, a);
     return hipGetLastError();
 }

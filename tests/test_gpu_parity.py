@@ -144,6 +144,30 @@ def test_full_size_postprocessing_exact_on_gpu_tensors(pkg, orc, synth):
         assert np.array_equal(r["coline_off"], ln["coline_off"]) and np.array_equal(r["coline_pairs"], ln["coline_pairs"])
 
 
+def test_refine_variants_vs_oracle(pkg, orc, synth):
+    """refineHeatMap with other tile sizes (8: the one-wave-per-tile kernel with quarter-filled lanes; 12: tiles with
+    remainders, one work-group per tile) and with a validity threshold below 2^-20, where the top-30 % mean is no longer
+    exact in any order and both kernels take their sorted, sequential summation."""
+    H, W = 96, 128
+    img = synth.make_frame(H, W, 77, 0, "dense")
+    for (sz, vth) in ((8, 1.0e-2), (12, 1.0e-2), (16, 1.0e-7), (12, 1.0e-7)):
+        gcfg = pkg.default_config(W, H, max_batch=1, max_num=500)
+        gcfg.heatmap_refine_sz = sz
+        gcfg.line_valid_thresh = vth
+        ctx = pkg.Context(gcfg)
+        try:
+            ctx.extract(img)
+            ocfg = orc.default_cfg(W, H)
+            ocfg.heatmap_refine_sz = sz
+            ocfg.line_valid_thresh = vth
+            refined = orc.refine_heat(ocfg, ctx.read_tensor(pkg.T_HEAT))
+            got = ctx.read_tensor(pkg.T_HEAT_REFINED)
+            assert np.array_equal(got, refined), (sz, vth, int(np.sum(got != refined)))
+            assert float(refined.max()) > 0.0
+        finally:
+            ctx.close()
+
+
 def test_batch_equals_single(pkg, synth):
     H, W = 96, 128
     imgs = [synth.make_frame(H, W, 40 + k, 0, "sparse" if k % 2 else "dense") for k in range(4)]
