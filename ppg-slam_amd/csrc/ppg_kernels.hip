@@ -368,6 +368,11 @@ __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, uns
 
 // KS = 1: a 1x1 layer has one tap per chunk, too little work between two barriers, so G chunks of 16 channels are staged
 // and consumed together (G = 2: 45 KiB of LDS).
+#ifdef PPG_CONV_TIMING
+// microbenchmark builds only (tools/ubench/conv_bench.hip): per work-group ticks (10 ns) of prologue, main loop and
+// epilogue of conv_bf16_kernel, summed, and the number of work-groups
+__device__ unsigned long long* g_conv_timing = nullptr;
+#endif
 template <int NT, bool FUSE1A, int MW, int TERMS, bool F16 = false, int KS = 3, int G = 1>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     static_assert(!FUSE1A || (KS == 3 && G == 1), "the fused first layer is 3x3");
@@ -390,6 +395,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     float* w1s = patch + PH * PW;                             // [9][64]
     float* b1s = w1s + 9 * 64;                                // [64]
 
+#ifdef PPG_CONV_TIMING
+    const long long tm0 = wall_clock64();
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int bx = blockIdx.x;
     const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, b = bx / (a.tiles_x * a.tiles_y);
@@ -510,6 +518,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     fetch(0);
     stash();
     __syncthreads();
+#ifdef PPG_CONV_TIMING
+    const long long tm1 = wall_clock64();
+#endif
     const unsigned char* ins = smem;
     const unsigned char* ws = smem + IN_BYTES_P;
     auto mma = [](bf16x8 wv, bf16x8 xv, f32x16 c) {
@@ -552,6 +563,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
         if (c + 1 < nchunks) stash();
         __syncthreads();
     }
+#ifdef PPG_CONV_TIMING
+    const long long tm2 = wall_clock64();
+#endif
     if (F16) {
         if (saturated && a.sat) atomicOr(a.sat, 1);
 #pragma unroll
@@ -562,6 +576,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
                 for (int r = 0; r < 16; r++) acc[m][n][r] *= kF16AccUnscale;
     }
     conv_store<NT, MW>(a, acc, wave, li, lh, x0, y0, b, nb);
+#ifdef PPG_CONV_TIMING
+    if (tid == 0 && g_conv_timing) {
+        const long long tm3 = wall_clock64();
+        atomicAdd(&g_conv_timing[0], (unsigned long long)(tm1 - tm0));
+        atomicAdd(&g_conv_timing[1], (unsigned long long)(tm2 - tm1));
+        atomicAdd(&g_conv_timing[2], (unsigned long long)(tm3 - tm2));
+        atomicAdd(&g_conv_timing[3], 1ull);
+    }
+#endif
 }
 
 int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }

@@ -1,5 +1,6 @@
 // Isolated timing of the convolution kernel on the layer shapes of the 640x480 front-end (batch 16).
 // Usage: conv_bench <0 zeros | 1 random | 2 small positive | 3 denormal-range inputs> [batch] [precision 0|1|2]
+#define PPG_CONV_TIMING 1
 #include "../../ppg-slam_amd/csrc/ppg_kernels.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +65,8 @@ int main(int argc, char** argv) {
     hipStream_t s2; hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
     long long* dclk; hipMalloc(&dclk, 16); long long hclk[2];
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    unsigned long long* dtim; hipMalloc(&dtim, 32);
+    hipMemcpyToSymbol(HIP_SYMBOL(ppg::g_conv_timing), &dtim, sizeof(dtim));
     for (const L& l : ls) {
         if (prec && (l.ks != 3 || l.nt != 2)) continue;
         ConvArgs a{};
@@ -77,6 +80,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 3; i++) launch_conv(a, l.ks, l.nt, 0);
         hipDeviceSynchronize();
         const int reps = 10;
+        hipMemset(dtim, 0, 32);
         float est; { hipEventRecord(e0); launch_conv(a, l.ks, l.nt, 0); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&est, e0, e1); }
         hipEventRecord(e0);
         clock_probe<<<1, 64, 0, s2>>>(dclk, (long long)(est * reps * 0.8 * 1e5));
@@ -86,8 +90,11 @@ int main(int argc, char** argv) {
         double fl = 2.0 * B * l.H * l.W * l.Cin * l.Cout * l.ks * l.ks;
         hipStreamSynchronize(s2);
         hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost);
-        printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  blocks=%d  clk=%.0f MHz\n", (int)rnd, l.name, ms * 1e3, fl / ms / 1e9,
-               a.tiles_x * a.tiles_y * B * a.nblk, 100.0 * hclk[0] / hclk[1]);
+        unsigned long long htim[4];
+        hipMemcpy(htim, dtim, 32, hipMemcpyDeviceToHost);
+        const double nw = htim[3] ? (double)htim[3] : 1.0;
+        printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  blocks=%d  clk=%.0f MHz  wg us: prologue %.2f main %.2f epilogue %.2f\n", (int)rnd, l.name, ms * 1e3, fl / ms / 1e9,
+               a.tiles_x * a.tiles_y * B * a.nblk, 100.0 * hclk[0] / hclk[1], htim[0] / nw * 0.01, htim[1] / nw * 0.01, htim[2] / nw * 0.01);
     }
     return 0;
 }
