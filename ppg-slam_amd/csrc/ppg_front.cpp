@@ -90,6 +90,8 @@ struct Slot {
     float* h_edge_score = nullptr;
     int32_t *h_conn_off = nullptr, *h_coline_off = nullptr;
     hipEvent_t cnn_done = nullptr;
+    hipEvent_t junc_done = nullptr;    // the junction logits are complete (the key-point kernels start beside the last three convolutions)
+    hipEvent_t heat_done = nullptr;    // EdgeHeatmap's convolutions are complete (the line kernels need nothing else)
     hipEvent_t match_done = nullptr;   // the batch's match against the previous one and its copies (match stream)
     // everything the host reads of a batch lies in one device block and one pinned block of the same layout, so a
     // full batch comes back in a single copy (with one frame per call thirteen small copies were a tenth of the call)
@@ -791,6 +793,8 @@ void ppg_destroy(ppg_ctx* c) {
     for (Slot& sl : c->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.cnn_done) (void)hipEventDestroy(sl.cnn_done);
+        if (sl.junc_done) (void)hipEventDestroy(sl.junc_done);
+        if (sl.heat_done) (void)hipEventDestroy(sl.heat_done);
         if (sl.match_done) (void)hipEventDestroy(sl.match_done);
     }
     if (c->ev_desc_ready) (void)hipEventDestroy(c->ev_desc_ready);
@@ -970,6 +974,8 @@ static int create_impl(ppg_ctx* c) {
         HIPCHK(c, hipMemset(sl.counters, 0, sizeof(int) * 8 * B));
         HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&sl.cnn_done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.junc_done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.heat_done, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&sl.match_done, hipEventDisableTiming));
         sl.frames.resize(B);
         sl.nkp.assign(B, 0);
@@ -1085,9 +1091,11 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     // PointHeatmap (junction_decoder.py:14-15)
     RC(run_heads(c, n, H / 8, W / 8));  // convPa + convDa + EdgeHeatmap block 0
     RC(run_conv(c, c->pb, c->pa_o, c->junc, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
+    HIPCHK(c, hipEventRecord(c->slot[c->cur].junc_done, c->stream));
     // EdgeHeatmap (heatmap_decoder.py:19-22); the last 1x1 conv runs in ppg_detect_lines' first kernel
     RC(run_conv(c, c->h1, c->hs0, c->hs1, n, H / 4, W / 4, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h2, c->hs1, c->hs2, n, H / 2, W / 2, ppg::CONV_PS2, 1));
+    HIPCHK(c, hipEventRecord(c->slot[c->cur].heat_done, c->stream));
     // Descriptor (descriptor_decoder.py:14-15)
     RC(run_conv(c, c->db, c->da_o, c->descmap, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
 #undef RC
@@ -1100,7 +1108,7 @@ int ppg_detect_keypoints(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].junc_done, 0));
     ProfScope ps(c, PPG_PROF_POST, c->post);
     HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(int) * 8 * n, c->post));
     ppg::NmsArgs a = nms_args(c, n);
@@ -1113,7 +1121,7 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].heat_done, 0));
     ProfScope ps(c, PPG_PROF_LINES, c->post);
     ppg::HeatArgs ha = heat_args(c, n);
     // last layer of EdgeHeatmap (1x1 conv 4->2, heatmap_decoder.py:22) fused with the 2-way softmax of :242
