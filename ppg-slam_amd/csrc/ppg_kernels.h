@@ -213,6 +213,7 @@ struct FusedMatchArgs {
     float th, ratio;
     float* norm_work;                     // [2][batch][maxn] work
     uint16_t* half_work;                  // [2][batch][maxn][256] work: the rows in fp16 (16-byte aligned)
+    float* bt_work;                       // [batch][256][maxn] work: B column-major
     int* list_cnt;                        // [batch][maxn] work
     uint16_t* list_col;                   // [batch][maxn][64] work
     float* list_rad;                      // [batch][maxn] work

@@ -1883,9 +1883,8 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
     __shared__ int deg[LT_MAXPTS + 1];
     __shared__ int cur[LT_MAXPTS + 1];
     __shared__ int part[1024];
-    __shared__ int wtot[16];
     __shared__ int s_flag;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     int* cnt = a.counters + b * 8;
     const int n = cnt[3], nc = cnt[2];
     int32_t* conn_off = a.conn_off + (size_t)b * (a.max_num + 1);
@@ -1914,51 +1913,104 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
         if (!(s & (CS_HAS_RI | CS_HAS_RJ))) s |= CS_ACC_KNOWN | CS_ACC;
         cst[k] = s;
     }
-    for (int p = tid; p < np; p += 1024) {   // kills at the first end point are attempted whatever happens to c (:316-335)
+    // A thread's first LR_PR pairs stay in registers for all rounds, and every pass first issues all its loads and then
+    // works on the results: one work-group per frame makes this kernel a chain of memory latencies, and a pass that
+    // walks its pairs one by one pays two of them per pair.
+    constexpr int LR_PR = 8;
+    uint32_t pw[LR_PR], pc[LR_PR];
+#pragma unroll
+    for (int q = 0; q < LR_PR; q++) {
+        const int p = tid + 1024 * q;
+        pw[q] = p < np ? pairs[2 * p + 1] : 0u;
+        pc[q] = p < np ? pairs[2 * p] : 0xFFFFFFFFu;   // 0xFFFFFFFF: no pair
+    }
+    auto is_kill_i = [](uint32_t w) { return (w >> 31) && !((w >> 30) & 1u); };
+    auto is_kill_j = [](uint32_t w) { return (w >> 31) && ((w >> 30) & 1u); };
+#pragma unroll
+    for (int q = 0; q < LR_PR; q++)   // kills at the first end point are attempted whatever happens to c (:316-335)
+        if (pc[q] != 0xFFFFFFFFu && is_kill_i(pw[q])) atomicMin(&kill_t[pw[q] & 0xFFFFu], pc[q]);
+    for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
         const uint32_t w = pairs[2 * p + 1];
-        if ((w >> 31) && !((w >> 30) & 1u)) atomicMin(&kill_t[w & 0xFFFFu], pairs[2 * p]);
+        if (is_kill_i(w)) atomicMin(&kill_t[w & 0xFFFFu], pairs[2 * p]);
     }
     __syncthreads();
     for (int round = 0; round <= nc; round++) {
         for (int k = tid; k < nc; k += 1024) pend_t[k] = LT_INF;
         __syncthreads();
-        for (int p = tid; p < np; p += 1024) {   // kills at the second end point happen only if c got past the first (:336-337)
+        // kills at the second end point happen only if c got past the first (:336-337)
+        {
+            uint32_t sq[LR_PR];
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++) sq[q] = (pc[q] != 0xFFFFFFFFu && is_kill_j(pw[q])) ? cst[pc[q]] : 0u;
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++) {
+                if (pc[q] == 0xFFFFFFFFu || !is_kill_j(pw[q])) continue;
+                if (sq[q] & CS_RI_KNOWN) { if (!(sq[q] & CS_RI)) atomicMin(&kill_t[pw[q] & 0xFFFFu], pc[q]); }
+                else atomicMin(&pend_t[pw[q] & 0xFFFFu], pc[q]);
+            }
+        }
+        for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
             const uint32_t w = pairs[2 * p + 1];
-            if (!((w >> 31) && ((w >> 30) & 1u))) continue;
+            if (!is_kill_j(w)) continue;
             const uint32_t c = pairs[2 * p], s = cst[c];
             if (s & CS_RI_KNOWN) { if (!(s & CS_RI)) atomicMin(&kill_t[w & 0xFFFFu], c); }
             else atomicMin(&pend_t[w & 0xFFFFu], c);
         }
         __syncthreads();
-        for (int p = tid; p < np; p += 1024) {   // is the partner that would reject c alive when c arrives?
+        // is the partner that would reject c alive when c arrives?
+        auto reject_bit = [&](uint32_t c, uint32_t w, uint32_t s, uint32_t sy, uint32_t kt, uint32_t pt) {
+            const uint32_t ep = (w >> 30) & 1u;
+            if (s & CS_ACC_KNOWN) return;
+            if (!ep && (s & CS_RI_KNOWN)) return;
+            if (((sy & CS_ACC_KNOWN) && !(sy & CS_ACC)) || kt < c) return;                      // dead or never listed
+            uint32_t bit;
+            if ((sy & CS_ACC_KNOWN) && pt > c) bit = ep ? CS_AJ_T : CS_AI_T;                   // alive
+            else bit = ep ? CS_AJ_U : CS_AI_U;                                                  // not settled yet
+            atomicOr(&cst[c], bit);
+        };
+        {
+            uint32_t s_[LR_PR], sy_[LR_PR], kt_[LR_PR], pt_[LR_PR];
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++) {
+                const bool on = pc[q] != 0xFFFFFFFFu && !(pw[q] >> 31);
+                const uint32_t y = pw[q] & 0xFFFFu;
+                s_[q] = on ? cst[pc[q]] : CS_ACC_KNOWN;
+                sy_[q] = on ? cst[y] : 0u;
+                kt_[q] = on ? kill_t[y] : 0u;
+                pt_[q] = on ? pend_t[y] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++)
+                if (pc[q] != 0xFFFFFFFFu && !(pw[q] >> 31)) reject_bit(pc[q], pw[q], s_[q], sy_[q], kt_[q], pt_[q]);
+        }
+        for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
             const uint32_t w = pairs[2 * p + 1];
             if (w >> 31) continue;
-            const uint32_t c = pairs[2 * p], s = cst[c], ep = (w >> 30) & 1u, y = w & 0xFFFFu;
-            if (s & CS_ACC_KNOWN) continue;
-            if (!ep && (s & CS_RI_KNOWN)) continue;
-            const uint32_t sy = cst[y];
-            uint32_t bit;
-            if (((sy & CS_ACC_KNOWN) && !(sy & CS_ACC)) || kill_t[y] < c) continue;             // dead or never listed
-            if ((sy & CS_ACC_KNOWN) && pend_t[y] > c) bit = ep ? CS_AJ_T : CS_AI_T;               // alive
-            else bit = ep ? CS_AJ_U : CS_AI_U;                                                    // not settled yet
-            atomicOr(&cst[c], bit);
+            const uint32_t c = pairs[2 * p], y = w & 0xFFFFu;
+            reject_bit(c, w, cst[c], cst[y], kill_t[y], pend_t[y]);
         }
         __syncthreads();
         int open = 0;
-        for (int k = tid; k < nc; k += 1024) {
-            uint32_t s = cst[k];
-            if (s & CS_ACC_KNOWN) continue;
-            if (!(s & CS_RI_KNOWN)) {
-                if (s & CS_AI_T) s |= CS_RI_KNOWN | CS_RI | CS_ACC_KNOWN;        // rejected at i: never listed
-                else if (!(s & CS_AI_U)) s |= CS_RI_KNOWN;
+        for (int k0 = tid; k0 < nc; k0 += 4 * 1024) {
+            uint32_t sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) sv[u] = k0 + 1024 * u < nc ? cst[k0 + 1024 * u] : CS_ACC_KNOWN;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t s = sv[u];
+                if (s & CS_ACC_KNOWN) continue;
+                if (!(s & CS_RI_KNOWN)) {
+                    if (s & CS_AI_T) s |= CS_RI_KNOWN | CS_RI | CS_ACC_KNOWN;        // rejected at i: never listed
+                    else if (!(s & CS_AI_U)) s |= CS_RI_KNOWN;
+                }
+                if ((s & CS_RI_KNOWN) && !(s & CS_RI) && !(s & CS_ACC_KNOWN)) {
+                    if (s & CS_AJ_T) s |= CS_ACC_KNOWN;
+                    else if (!(s & CS_AJ_U)) s |= CS_ACC_KNOWN | CS_ACC;
+                }
+                s &= ~(CS_AI_T | CS_AI_U | CS_AJ_T | CS_AJ_U);
+                cst[k0 + 1024 * u] = s;
+                open += !(s & CS_ACC_KNOWN);
             }
-            if ((s & CS_RI_KNOWN) && !(s & CS_RI) && !(s & CS_ACC_KNOWN)) {
-                if (s & CS_AJ_T) s |= CS_ACC_KNOWN;
-                else if (!(s & CS_AJ_U)) s |= CS_ACC_KNOWN | CS_ACC;
-            }
-            s &= ~(CS_AI_T | CS_AI_U | CS_AJ_T | CS_AJ_U);
-            cst[k] = s;
-            open += !(s & CS_ACC_KNOWN);
         }
         if (__syncthreads_count(open) == 0) { if (tid == 0) cnt[7] |= (round + 1) << 8; break; }
     }
@@ -1973,42 +2025,64 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
     __syncthreads();
 
     // ---- score thresholds (:367-389) and ordered compaction (:433-441) ----
-    uint32_t* e2k = pend_t;   // edge -> candidate (pend_t is free now; e <= k, and a chunk is read before it is written)
-    int ebase = 0;
-    for (int base = 0; base < nc; base += 1024) {
-        const int k = base + tid;
-        bool keep = false;
-        float inl = 0.f, sh = 0.f;
-        uint32_t ij = 0;
-        if (k < nc) {
-            const uint32_t s = cst[k];
-            keep = (s & CS_ACC) && kill_t[k] == LT_INF;
-            if (keep) {
-                inl = csc[2 * k]; sh = csc[2 * k + 1];
-                if (inl < a.inlier_rate) keep = false;
-                else if (sh < a.heat_thresh) keep = false;
-                ij = cij[k];
-            }
+    // A thread takes a run of consecutive candidates: it decides them from loads issued together, the runs' survivor counts
+    // go through one scan, and the survivors are written at their ordered positions.
+    uint32_t* e2k = pend_t;   // edge -> candidate (pend_t is free now)
+    const int per = (nc + 1023) / 1024;   // <= 64: tail_cap <= 65536
+    const int kbeg = tid * per, kend = min(nc, kbeg + per);
+    unsigned long long keepm = 0ull;
+    for (int i0 = 0; i0 < per; i0 += 8) {
+        uint32_t s8[8], kt8[8];
+        f32x2 sc8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = kbeg + i0 + u;
+            const bool in = i0 + u < per && k < kend;
+            s8[u] = in ? cst[k] : 0u;
+            kt8[u] = in ? kill_t[k] : 0u;
+            sc8[u] = in ? *(const f32x2*)(csc + 2 * (size_t)k) : f32x2{0.f, 0.f};
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wtot[wave] = __popcll(m);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            bool keep = (s8[u] & CS_ACC) && kt8[u] == LT_INF;
+            if (keep) {
+                if (sc8[u][0] < a.inlier_rate) keep = false;
+                else if (sc8[u][1] < a.heat_thresh) keep = false;
+            }
+            if (keep) keepm |= 1ull << (i0 + u);
+        }
+    }
+    const int mine_cnt = __popcll(keepm);
+    part[tid] = mine_cnt;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+        const int v = tid >= o ? part[tid - o] : 0;
         __syncthreads();
-        int off = ebase, tot = 0;
-        for (int w = 0; w < 16; w++) { if (w < wave) off += wtot[w]; tot += wtot[w]; }
-        if (keep) {
-            const int e = off + __popcll(m & ((1ull << lane) - 1ull));
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int ebase = part[1023];
+    {
+        int e = part[tid] - mine_cnt;
+        unsigned long long m = keepm;
+        while (m) {
+            const int i = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int k = kbeg + i;
             if (e < a.edge_cap) {
+                const uint32_t ij = cij[k];
+                const f32x2 sc = *(const f32x2*)(csc + 2 * (size_t)k);
                 a.edge_idx[((size_t)b * a.edge_cap + e) * 2] = ij >> 16;
                 a.edge_idx[((size_t)b * a.edge_cap + e) * 2 + 1] = ij & 0xFFFFu;
-                a.edge_score[(size_t)b * a.edge_cap + e] = inl * sh;
+                a.edge_score[(size_t)b * a.edge_cap + e] = sc[0] * sc[1];
                 e2k[e] = (uint32_t)k;
                 atomicAdd(&deg[ij >> 16], 1);
                 atomicAdd(&deg[ij & 0xFFFFu], 1);
             }
+            e++;
         }
-        ebase += tot;
-        __syncthreads();
     }
+    __syncthreads();
     const int E = ebase;
     if (E > a.edge_cap) {
         if (tid == 0) atomicOr(&cnt[5], LT_CAP);
@@ -2779,8 +2853,34 @@ __global__ __launch_bounds__(256) void match_exact_kernel(PrefilterArgs a, int32
     if (lane == 0) near_len[(size_t)b * a.maxn + row] = len;
 }
 
+// Bt[b][d][col] = B[b][col][d]: the column-major copy the claim pass scans when a row needs all its distances (a thread
+// per column then reads consecutive addresses; from the row-major descriptors every lane walks its own row, 64 cache
+// lines per load instruction, and a scan of 1024 columns by one CU takes 35 us instead of 8).  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void desc_transpose_kernel(const float* __restrict__ B, const int* n_dev, int sn, int n_host,
+                                                             int maxn, size_t sB, float* __restrict__ Bt) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z;
+    const int n = n_dev ? min(maxn, n_dev[b * sn]) : n_host;
+    const int c0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    if (c0 >= n) return;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 16; idx += 256) {
+        const int r = idx >> 4, q = idx & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c0 + r < n) v = *(const f32x4*)(B + b * sB + (size_t)(c0 + r) * 256 + d0 + 4 * q);
+        tile[r][4 * q] = v[0]; tile[r][4 * q + 1] = v[1]; tile[r][4 * q + 2] = v[2]; tile[r][4 * q + 3] = v[3];
+    }
+    __syncthreads();
+    float* out = Bt + (size_t)b * 256 * maxn;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int d = idx >> 6, r = idx & 63;
+        if (c0 + r < maxn) out[(size_t)(d0 + d) * maxn + c0 + r] = tile[r][d];
+    }
+}
+
 struct JacobiArgs {
     const float* A; const float* B; size_t sA, sB;
+    const float* Bt;    // [batch][256][maxn] column-major copy of B
     const int* nA_dev; const int* nB_dev; int sn;
     int nA, nB;
     int maxn;
@@ -2806,7 +2906,6 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
     const float* A = a.A + b * a.sA;
-    const float* B = a.B + b * a.sB;
     // thread i owns row i (nA <= 1024); its sorted nearest list stays in registers for every round
     const int i = tid;
     float nd[PF_NEAR];
@@ -2878,11 +2977,11 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
             for (int rr = 0; rr < JB_FB; rr++) acc[rr] = 0.f;
             const int col = tid;
             if (col < nB) {
-                const float* y = B + (size_t)col * 256;
+                const float* y = a.Bt + (size_t)b * 256 * a.maxn + col;   // component d of this column at y[d * maxn]
                 for (int d = 0; d < 256; d += 16) {
-                    f32x4 v[4];
+                    float v[16];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) v[q] = *(const f32x4*)(y + d + 4 * q);
+                    for (int q = 0; q < 16; q++) v[q] = y[(size_t)(d + q) * a.maxn];
 #pragma unroll
                     for (int rr = 0; rr < JB_FB; rr++) {
                         if (rr >= nb) continue;   // uniform
@@ -2891,7 +2990,7 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
                             const f32x4 u = *(const f32x4*)&xs[rr][d + 4 * q];
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                const float t = u[e] - v[q][e];
+                                const float t = u[e] - v[4 * q + e];
                                 acc[rr] = fmaf(t, t, acc[rr]);
                             }
                         }
@@ -2962,8 +3061,9 @@ hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
     if (!(f.debug_skip & 4)) hipLaunchKernelGGL(match_prefilter_kernel, dim3((f.maxn + PF_ROWS - 1) / PF_ROWS, f.batch), dim3(PF_THREADS), 0, s, p);
     if (!(f.debug_skip & 2)) hipLaunchKernelGGL(match_exact_kernel, gn, dim3(256), 0, s, p, f.near_idx, f.near_dist, f.near_len);
     if (f.debug_skip & 1) return hipGetLastError();
+    hipLaunchKernelGGL(desc_transpose_kernel, dim3((f.maxn + 63) / 64, 4, f.batch), dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.nB, f.maxn, f.sB, f.bt_work);
     JacobiArgs j;
-    j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
+    j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.Bt = f.bt_work; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
     j.nA = f.nA; j.nB = f.nB;
     j.near_idx = f.near_idx; j.near_dist = f.near_dist; j.near_len = f.near_len; j.th = f.th; j.ratio = f.ratio; j.match12 = f.match12;
     j.best = f.best; j.second = f.second; j.n_matches = f.n_matches; j.stats = f.stats;
