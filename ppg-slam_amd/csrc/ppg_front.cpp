@@ -214,6 +214,7 @@ struct ppg_ctx {
     DBuf<float> mListRad;
     DBuf<uint16_t> mListCol, mHalf;
     DBuf<float> mBt;
+    DBuf<unsigned long long> mExt;
     // device copy of the vocabulary last used with ppg_bow_transform*
     unsigned long long voc_serial = 0;
     float* voc_desc = nullptr;
@@ -786,7 +787,7 @@ void ppg_destroy(ppg_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
-                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mHalf.p, c->mBt.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p, c->mSkipOut.p, c->mRowClaims.p, c->xArena.p,
+                  c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mHalf.p, c->mBt.p, c->mExt.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p, c->mSkipOut.p, c->mRowClaims.p, c->xArena.p,
                   c->voc_desc, c->voc_child_off, c->voc_child_idx, c->voc_word, c->voc_weight};
     for (void* p : ms)
         if (p) (void)hipFree(p);
@@ -1532,6 +1533,7 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     if (!rc && fused) rc = grow(c, c->mListCol, (size_t)std::max(nA, nB) * 64);
     if (!rc && fused) rc = grow(c, c->mHalf, (size_t)2 * std::max(nA, nB) * 256);
     if (!rc && fused) rc = grow(c, c->mBt, (size_t)std::max(nA, nB) * 256);
+    if (!rc && fused) rc = grow(c, c->mExt, (size_t)64 * 128);
     if (!rc) rc = grow(c, c->mMatch, nA);
     if (!rc) rc = grow(c, c->mBest, nA);
     if (!rc) rc = grow(c, c->mSecond, nA);
@@ -1550,7 +1552,7 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
         ppg::FusedMatchArgs f;
         f.A = c->mA.p; f.B = c->mB.p; f.sA = 0; f.sB = 0; f.nA_dev = nullptr; f.nB_dev = nullptr; f.sn = 0; f.nA = nA; f.nB = nB;
         f.maxn = std::max(nA, nB); f.batch = 1; f.th = th; f.ratio = ratio;
-        f.norm_work = c->mNorm.p; f.half_work = c->mHalf.p; f.bt_work = c->mBt.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
+        f.norm_work = c->mNorm.p; f.half_work = c->mHalf.p; f.bt_work = c->mBt.p; f.ext_work = c->mExt.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
         f.list_rad = c->mListRad.p; f.near_len = c->mNearLen.p;
         f.near_idx = c->mTopI.p; f.near_dist = c->mTopD.p; f.match12 = c->mMatch.p; f.best = c->mBest.p; f.second = c->mSecond.p;
         f.n_matches = c->mCount;
@@ -1992,6 +1994,7 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
     if (!rc && fused) rc = grow(c, c->mListCol, (size_t)M * batch * 64);
     if (!rc && fused) rc = grow(c, c->mHalf, (size_t)2 * M * batch * 256);
     if (!rc && fused) rc = grow(c, c->mBt, (size_t)M * batch * 256);
+    if (!rc && fused) rc = grow(c, c->mExt, (size_t)batch * 64 * 128);
     if (rc) return rc;
     // the descriptors come from the post stream; the matcher's work arrays belong to the match stream
     hipStream_t s = c->match_stream;
@@ -2003,7 +2006,7 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
         ppg::FusedMatchArgs f;
         f.A = dA; f.B = dB; f.sA = (size_t)M * 256; f.sB = (size_t)M * 256; f.nA_dev = nA; f.nB_dev = nB; f.sn = 8;
         f.maxn = M; f.batch = batch; f.th = 0.7f /* TH_LOW, Matcher.cpp:13 */; f.ratio = nnratio;
-        f.norm_work = c->mNorm.p; f.half_work = c->mHalf.p; f.bt_work = c->mBt.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
+        f.norm_work = c->mNorm.p; f.half_work = c->mHalf.p; f.bt_work = c->mBt.p; f.ext_work = c->mExt.p; f.list_cnt = c->mListCnt.p; f.list_col = c->mListCol.p;
         f.list_rad = c->mListRad.p; f.near_len = c->mNearLen.p;
         f.near_idx = c->mTopI.p; f.near_dist = c->mTopD.p; f.match12 = d_match; f.best = c->mBest.p; f.second = c->mSecond.p;
         f.n_matches = d_mcounts;

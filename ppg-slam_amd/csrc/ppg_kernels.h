@@ -214,6 +214,7 @@ struct FusedMatchArgs {
     float* norm_work;                     // [2][batch][maxn] work
     uint16_t* half_work;                  // [2][batch][maxn][256] work: the rows in fp16 (16-byte aligned)
     float* bt_work;                       // [batch][256][maxn] work: B column-major
+    unsigned long long* ext_work;         // [batch][64][128] work: extended lists of the claim pass
     int* list_cnt;                        // [batch][maxn] work
     uint16_t* list_col;                   // [batch][maxn][64] work
     float* list_rad;                      // [batch][maxn] work

@@ -2881,6 +2881,7 @@ __global__ __launch_bounds__(256) void desc_transpose_kernel(const float* __rest
 struct JacobiArgs {
     const float* A; const float* B; size_t sA, sB;
     const float* Bt;    // [batch][256][maxn] column-major copy of B
+    uint2* ext;         // [batch][JB_EXT_ROWS][JB_EXT_LEN] work: (distance bits, column) lists written by whole-row scans
     const int* nA_dev; const int* nB_dev; int sn;
     int nA, nB;
     int maxn;
@@ -2894,6 +2895,7 @@ struct JacobiArgs {
 };
 
 constexpr int JB_FB = 8;   // rows of one whole-row scan pass
+constexpr int JB_EXT_ROWS = 64, JB_EXT_LEN = 128;   // rows that can keep an extended list after a whole-row scan, entries of one
 
 __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
     __shared__ uint32_t claim[PF_MAXCOLS];     // smallest row whose current guess is this column
@@ -2903,9 +2905,19 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
     __shared__ float rb[JB_FB][16], rs[JB_FB][16];
     __shared__ int rp[JB_FB][16];
     __shared__ __attribute__((aligned(16))) float xs[JB_FB][256];
+    // After a whole-row scan the row keeps every column up to its second-best free one (claimed ones included) as an
+    // unsorted list: all columns within that radius, so the two nearest free entries of the list are the row's two nearest
+    // free columns whatever the claims become, and the row is scanned again only if the list runs dry in its turn.
+    __shared__ int ext_n;                       // rows that own a list
+    __shared__ int ext_cnt[JB_EXT_ROWS];        // entries appended to each (may exceed JB_EXT_LEN: then the list is void)
+    __shared__ float fb_radius[JB_FB];
+    __shared__ int fb_slot[JB_FB];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
     const float* A = a.A + b * a.sA;
+    uint2* ext = a.ext + (size_t)b * JB_EXT_ROWS * JB_EXT_LEN;
+    int my_ext = -1;                            // this row's list, or -1
+    if (tid == 0) ext_n = 0;
     // thread i owns row i (nA <= 1024); its sorted nearest list stays in registers for every round
     const int i = tid;
     float nd[PF_NEAR];
@@ -2941,15 +2953,31 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
         if (i < nA) {
             float best = 1e6f, second = 1e6f;
             int bidx = -1, nfree = 0;
+            bool whole = len >= nB;   // the list at hand covers the whole row
+            if (my_ext >= 0) {
+                const int cnt = ext_cnt[my_ext];
+                const uint2* e = ext + (size_t)my_ext * JB_EXT_LEN;
+                whole = cnt >= nB;
+                for (int t = 0; t < cnt; t++) {   // unsorted: keep the two smallest free entries by (distance, column)
+                    const uint2 v = e[t];
+                    const int col = (int)v.y;
+                    if (claim[col] < (uint32_t)i) continue;
+                    const float d = __uint_as_float(v.x);
+                    if (d < best || (d == best && col < bidx)) { second = best; best = d; bidx = col; }
+                    else if (d < second) second = d;
+                    nfree++;
+                }
+            } else {
 #pragma unroll
-            for (int t = 0; t < PF_NEAR; t++) {
-                if (t >= len || nfree >= 2) continue;
-                if (claim[ni[t]] < (uint32_t)i) continue;   // claimed by an earlier row
-                if (nfree == 0) { best = nd[t]; bidx = ni[t]; }
-                else second = nd[t];
-                nfree++;
+                for (int t = 0; t < PF_NEAR; t++) {
+                    if (t >= len || nfree >= 2) continue;
+                    if (claim[ni[t]] < (uint32_t)i) continue;   // claimed by an earlier row
+                    if (nfree == 0) { best = nd[t]; bidx = ni[t]; }
+                    else second = nd[t];
+                    nfree++;
+                }
             }
-            if (nfree < 2 && len < nB) {
+            if (nfree < 2 && !whole) {
                 // the certain part of the list ran dry while the row has more columns: scan the whole row
                 fallback = true;
                 fb_rows[atomicAdd(&fb_n, 1)] = i;
@@ -3015,7 +3043,34 @@ __global__ __launch_bounds__(1024) void match_jacobi_kernel(JacobiArgs a) {
                     const int m = (q.pos >= 0 && q.b <= a.th && q.b < q.b2 * a.ratio) ? q.pos : -1;
                     if (m != mine) fb_changed = 1;
                     mine = m; mbest = q.b; msecond = q.b2;
+                    // the row's list from now on: every column up to the second-best free one (none if there is no such
+                    // column, if no list is left to hand out, or if the list would not fit)
+                    if (my_ext < 0 && q.b2 < 1e6f) {
+                        const int sl = atomicAdd(&ext_n, 1);
+                        if (sl < JB_EXT_ROWS) my_ext = sl;
+                    }
+                    if (my_ext >= 0) ext_cnt[my_ext] = 0;
+                    fb_slot[rr] = q.b2 < 1e6f ? my_ext : -1;
+                    fb_radius[rr] = q.b2;
                 }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < JB_FB; rr++) {
+                if (rr >= nb) continue;
+                const int sl = fb_slot[rr];
+                if (sl < 0 || col >= nB) continue;
+                const float d = sqrtf(acc[rr]);
+                if (d <= fb_radius[rr]) {
+                    const int o = atomicAdd(&ext_cnt[sl], 1);
+                    if (o < JB_EXT_LEN) ext[(size_t)sl * JB_EXT_LEN + o] = make_uint2(__float_as_uint(d), (uint32_t)col);
+                }
+            }
+            __syncthreads();
+            if (fallback && my_ext >= 0 && ext_cnt[my_ext] > JB_EXT_LEN) {
+                // does not fit: the row goes back to whole-row scans (its slot stays taken; this does not happen with
+                // real descriptors, where the second-best free column is a few dozen columns out)
+                my_ext = -1;
             }
             __syncthreads();
         }
@@ -3063,7 +3118,7 @@ hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
     if (f.debug_skip & 1) return hipGetLastError();
     hipLaunchKernelGGL(desc_transpose_kernel, dim3((f.maxn + 63) / 64, 4, f.batch), dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.nB, f.maxn, f.sB, f.bt_work);
     JacobiArgs j;
-    j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.Bt = f.bt_work; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
+    j.A = f.A; j.B = f.B; j.sA = f.sA; j.sB = f.sB; j.Bt = f.bt_work; j.ext = (uint2*)f.ext_work; j.nA_dev = f.nA_dev; j.nB_dev = f.nB_dev; j.sn = f.sn; j.maxn = f.maxn;
     j.nA = f.nA; j.nB = f.nB;
     j.near_idx = f.near_idx; j.near_dist = f.near_dist; j.near_len = f.near_len; j.th = f.th; j.ratio = f.ratio; j.match12 = f.match12;
     j.best = f.best; j.second = f.second; j.n_matches = f.n_matches; j.stats = f.stats;
