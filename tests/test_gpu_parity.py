@@ -833,6 +833,54 @@ def test_fused_match_equals_matrix_path(pkg, orc, synth, monkeypatch):
         ref.close()
 
 
+def test_fused_match_adversarial_descriptors(pkg, monkeypatch):
+    """All-pairs SearchForInitialization through ppg_match_nn on descriptor sets built to break the matrix-free path:
+    tight clusters (the prefilter lists overflow, the extended lists of the claim pass do not fit), exact duplicates
+    (ties at distance 0 and between rows), all-zero rows, very few columns, more rows than columns.  Bit-equal to the
+    path through the full distance matrix (PPG_MATCH_MATRIX=1) in matches, best and second-best distances."""
+    rng = np.random.default_rng(5)
+
+    def unit(x):
+        n = np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+        x = (x / np.maximum(n, np.float32(1e-20))).astype(np.float32)
+        # keep the squared norms at or below 1 (the fused path's precondition, which the library checks on host input)
+        return (x * np.float32(0.99999)).astype(np.float32)
+
+    def clustered(n, k, eps):
+        centres = unit(rng.normal(size=(k, 256)).astype(np.float32))
+        return unit(centres[rng.integers(0, k, n)] + eps * rng.normal(size=(n, 256)).astype(np.float32))
+
+    cases = []
+    cases.append(("clusters", clustered(1000, 6, 2e-3), clustered(1024, 6, 2e-3)))
+    cases.append(("tight clusters", clustered(900, 3, 1e-5), clustered(950, 3, 1e-5)))
+    base = unit(rng.normal(size=(40, 256)).astype(np.float32))
+    cases.append(("duplicates", base[rng.integers(0, 40, 800)], base[rng.integers(0, 40, 1024)]))
+    z = unit(rng.normal(size=(600, 256)).astype(np.float32))
+    z[::3] = 0.0
+    zb = unit(rng.normal(size=(700, 256)).astype(np.float32))
+    zb[::5] = 0.0
+    cases.append(("zero rows", z, zb))
+    cases.append(("three columns", unit(rng.normal(size=(700, 256)).astype(np.float32)), unit(rng.normal(size=(3, 256)).astype(np.float32))))
+    cases.append(("one column", unit(rng.normal(size=(64, 256)).astype(np.float32)), unit(rng.normal(size=(1, 256)).astype(np.float32))))
+    cases.append(("few rows", unit(rng.normal(size=(5, 256)).astype(np.float32)), unit(rng.normal(size=(900, 256)).astype(np.float32))))
+    noisy = unit(rng.normal(size=(1024, 256)).astype(np.float32))
+    cases.append(("same set", noisy, unit(noisy + 0.05 * rng.normal(size=noisy.shape).astype(np.float32))))
+    fused = pkg.Context(pkg.default_config(128, 96, max_batch=1, max_num=500))
+    monkeypatch.setenv("PPG_MATCH_MATRIX", "1")
+    ref = pkg.Context(pkg.default_config(128, 96, max_batch=1, max_num=500))
+    monkeypatch.delenv("PPG_MATCH_MATRIX")
+    try:
+        for name, A, B in cases:
+            for th, ratio in ((0.7, 0.9), (2.5, 1.0)):
+                mf, bf, sf, cf = fused.match_nn(A, B, th=th, ratio=ratio, mode=pkg.MATCH_INIT)
+                mr, br, sr, cr = ref.match_nn(A, B, th=th, ratio=ratio, mode=pkg.MATCH_INIT)
+                assert cf == cr and np.array_equal(mf, mr), (name, th, ratio, int(np.sum(mf != mr)))
+                assert np.array_equal(bf, br) and np.array_equal(sf, sr), (name, th, ratio)
+    finally:
+        fused.close()
+        ref.close()
+
+
 def test_waited_results_survive_the_next_submit(pkg, synth):
     """Four batches in flight, the bench's pattern: the buffers behind the frames that ppg_wait_batch hands out must
     still hold that batch after ONE more submit (the ring has one slot more than may be in flight)."""
