@@ -222,6 +222,7 @@ struct ppg_ctx {
     double* voc_weight = nullptr;
     DBuf<int32_t> bWord, bNode;
     DBuf<double> bWeight;
+    bool no_quarter = false;    // PPG_NO_QUARTER_TILES=1: big convolution tiles whatever the batch size (read at ppg_create)
     bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
     int* mCount = nullptr;
     int* h_mcount = nullptr;
@@ -647,13 +648,12 @@ void undistort_rectify_maps(const ppg_config& c, std::vector<float>& mx, std::ve
 // kQuarterBelow work-groups on the chip (256 CUs take three each) goes out in quarter-size work-groups instead: with
 // one or two frames per call the deep layers are 20 to 300 big tiles, and the launch lasts as long as one of them.
 constexpr int kQuarterBelow = 600;
-void conv_tiling(ppg::ConvArgs& a, const DevConv& dc, int mode, bool fused) {
+void conv_tiling(const ppg_ctx* c, ppg::ConvArgs& a, const DevConv& dc, int mode, bool fused) {
     const int H = a.H, W = a.W;
     a.mw = fused ? 32 : pick_tile(dc, H, W, mode);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
     a.quarter = 0;
-    static const bool never = getenv("PPG_NO_QUARTER_TILES") != nullptr;
-    if (never || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
+    if (c->no_quarter || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
     if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;
     a.quarter = 1;
     // pooling pairs the two rows of an 8 x 16 tile's pixel tiles; otherwise the shape with the least padded area
@@ -676,7 +676,7 @@ int run_conv(ppg_ctx* c, const DevConv& dc, const float* in, float* out, int n, 
     a.in = in; a.wpk = dc.w; a.prec = dc.lowp ? c->cfg.precision : 0; a.sat = c->slot[c->cur].sat;
     a.B = n; a.H = H; a.W = W; a.Cin = dc.cin;
     a.nblk = dc.nblk;
-    conv_tiling(a, dc, mode, fused_img != nullptr);
+    conv_tiling(c, a, dc, mode, fused_img != nullptr);
     a.ngroups = 1;
     a.g[0] = conv_group(dc, out, mode, relu, 0);
     const int cls = fused_img ? PPG_PROF_CONV1A : (dc.ks == 3 && dc.nt == 2 ? PPG_PROF_CONV3X3 : PPG_PROF_CONV_OTHER);
@@ -693,7 +693,7 @@ int run_heads(ppg_ctx* c, int n, int H, int W) {
     a.in = c->feat; a.wpk = c->heads_w; a.prec = c->pa.lowp ? c->cfg.precision : 0; a.sat = c->slot[c->cur].sat;
     a.B = n; a.H = H; a.W = W; a.Cin = c->pa.cin;
     a.nblk = c->pa.nblk + c->da.nblk + c->h0.nblk;
-    conv_tiling(a, c->pa, ppg::CONV_PLAIN, false);
+    conv_tiling(c, a, c->pa, ppg::CONV_PLAIN, false);
     a.ngroups = 3;
     a.g[0] = conv_group(c->pa, c->pa_o, ppg::CONV_PLAIN, 1, 0);
     a.g[1] = conv_group(c->da, c->da_o, ppg::CONV_PLAIN, 1, c->pa.nblk);
@@ -855,6 +855,8 @@ static int create_impl(ppg_ctx* c) {
         c->dump_tail = getenv("PPG_DUMP_TAIL");
         const char* mm = getenv("PPG_MATCH_MATRIX");
         c->match_matrix = mm && atoi(mm) != 0;
+        const char* nq = getenv("PPG_NO_QUARTER_TILES");
+        c->no_quarter = nq && atoi(nq) != 0;
         const char* eh = getenv("PPG_EXTEND_HOST");
         c->extend_on_host = eh && atoi(eh) != 0;
         const char* lh = getenv("PPG_LINES_HOST");

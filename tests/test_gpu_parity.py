@@ -168,6 +168,29 @@ def test_refine_variants_vs_oracle(pkg, orc, synth):
             ctx.close()
 
 
+def test_quarter_tiles_equal_big_tiles(pkg, synth, monkeypatch):
+    """Small batches run the fp32 3x3 layers in quarter-size work-groups (4x32 / 8x16 pixels x 32 couts, pooling inside
+    the 8x16 tile); PPG_NO_QUARTER_TILES=1 keeps the big tiles.  Every network output must be bit-identical, on even
+    and on ragged sizes (the chain of every output is the same in both tilings)."""
+    for (H, W, n) in ((480, 640, 1), (96, 128, 3), (72, 104, 2), (120, 136, 1)):
+        imgs = [synth.make_frame(H, W, 610 + k, 0, "dense" if k % 2 else "sparse") for k in range(n)]
+        small = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500))
+        monkeypatch.setenv("PPG_NO_QUARTER_TILES", "1")
+        big = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500))
+        monkeypatch.delenv("PPG_NO_QUARTER_TILES")
+        try:
+            rs, rb = small.extract_batch(imgs), big.extract_batch(imgs)
+            for which in (pkg.T_FEAT, pkg.T_JUNC, pkg.T_HEAT_RAW, pkg.T_DESCMAP, pkg.T_SCORE, pkg.T_HEAT):
+                for f in range(n):
+                    assert np.array_equal(small.read_tensor(which, f), big.read_tensor(which, f)), (H, W, n, which, f)
+            for a, b in zip(rs, rb):
+                assert np.array_equal(a["xy"], b["xy"]) and np.array_equal(a["desc"], b["desc"])
+                assert np.array_equal(a["edge_idx"], b["edge_idx"])
+        finally:
+            small.close()
+            big.close()
+
+
 def test_batch_equals_single(pkg, synth):
     H, W = 96, 128
     imgs = [synth.make_frame(H, W, 40 + k, 0, "sparse" if k % 2 else "dense") for k in range(4)]
