@@ -1879,9 +1879,171 @@ __global__ __launch_bounds__(256) void line_inter_kernel(LineTailArgs a) {
 constexpr int LT_MAXPTS = 4096;   // junction_max_num limit of the library
 constexpr int LT_MAXDEG = 32;     // incident surviving lines per point the collinearity search holds in registers
 
+// Where the relaxation keeps its three per-candidate arrays: in global memory (any frame), or as 16-bit entries in LDS
+// (frames of at most LR_NC_LDS candidates, i.e. nearly all): with one work-group per frame every pass of a round is a
+// round trip to wherever the arrays live, and the L2 is ten times farther than the LDS.
+constexpr int LR_NC_LDS = 20480;
+struct LrGlobal {
+    uint32_t *cst, *kill, *pend;
+    __device__ uint32_t get_cst(uint32_t k) const { return cst[k]; }
+    __device__ void set_cst(uint32_t k, uint32_t v) const { cst[k] = v; }
+    __device__ void or_cst(uint32_t k, uint32_t bits) const { atomicOr(&cst[k], bits); }
+    __device__ uint32_t get_kill(uint32_t k) const { return kill[k]; }
+    __device__ void min_kill(uint32_t k, uint32_t c) const { atomicMin(&kill[k], c); }
+    __device__ uint32_t get_pend(uint32_t k) const { return pend[k]; }
+    __device__ void min_pend(uint32_t k, uint32_t c) const { atomicMin(&pend[k], c); }
+    __device__ void clear_pend(uint32_t k) const { pend[k] = LT_INF; }
+};
+struct LrLds {   // 16-bit entries, 0xFFFF = LT_INF (candidate indices stay below LR_NC_LDS)
+    uint16_t *cst, *kill, *pend;
+    __device__ static uint32_t widen(uint16_t v) { return v == 0xFFFFu ? LT_INF : (uint32_t)v; }
+    __device__ static void min16(uint16_t* arr, uint32_t k, uint32_t c) {
+        uint32_t* w = (uint32_t*)arr + (k >> 1);
+        const int sh = 16 * (int)(k & 1u);
+        uint32_t old = *w;
+        while (true) {
+            if (((old >> sh) & 0xFFFFu) <= c) break;
+            const uint32_t nw = (old & ~(0xFFFFu << sh)) | (c << sh);
+            const uint32_t prev = atomicCAS(w, old, nw);
+            if (prev == old) break;
+            old = prev;
+        }
+    }
+    __device__ uint32_t get_cst(uint32_t k) const { return cst[k]; }
+    __device__ void set_cst(uint32_t k, uint32_t v) const { cst[k] = (uint16_t)v; }
+    __device__ void or_cst(uint32_t k, uint32_t bits) const { atomicOr((uint32_t*)cst + (k >> 1), bits << (16 * (k & 1u))); }
+    __device__ uint32_t get_kill(uint32_t k) const { return widen(kill[k]); }
+    __device__ void min_kill(uint32_t k, uint32_t c) const { min16(kill, k, c); }
+    __device__ uint32_t get_pend(uint32_t k) const { return widen(pend[k]); }
+    __device__ void min_pend(uint32_t k, uint32_t c) const { min16(pend, k, c); }
+    __device__ void clear_pend(uint32_t k) const { pend[k] = 0xFFFFu; }
+};
+
+// The sequential overlap pass (:315-337) as a relaxation over the classified pairs; on return st holds the final
+// "accepted" bits and kill times.  Returns the number of rounds.
+template <class S>
+__device__ int line_relax(const S st, const uint32_t* __restrict__ pairs, int np, int nc) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nc; k += 1024) {
+        uint32_t s = st.get_cst(k) & (CS_HAS_RI | CS_HAS_RJ);
+        if (!(s & CS_HAS_RI)) s |= CS_RI_KNOWN;                                    // nothing at i can reject it
+        if (!(s & (CS_HAS_RI | CS_HAS_RJ))) s |= CS_ACC_KNOWN | CS_ACC;
+        st.set_cst(k, s);
+    }
+    // A thread's first LR_PR pairs stay in registers for all rounds, and every pass first issues all its loads and then
+    // works on the results.
+    constexpr int LR_PR = 8;
+    uint32_t pw[LR_PR], pc[LR_PR];
+#pragma unroll
+    for (int q = 0; q < LR_PR; q++) {
+        const int p = tid + 1024 * q;
+        pw[q] = p < np ? pairs[2 * p + 1] : 0u;
+        pc[q] = p < np ? pairs[2 * p] : 0xFFFFFFFFu;   // 0xFFFFFFFF: no pair
+    }
+    auto is_kill_i = [](uint32_t w) { return (w >> 31) && !((w >> 30) & 1u); };
+    auto is_kill_j = [](uint32_t w) { return (w >> 31) && ((w >> 30) & 1u); };
+    __syncthreads();   // (the LDS variant was filled by other threads)
+#pragma unroll
+    for (int q = 0; q < LR_PR; q++)   // kills at the first end point are attempted whatever happens to c (:316-335)
+        if (pc[q] != 0xFFFFFFFFu && is_kill_i(pw[q])) st.min_kill(pw[q] & 0xFFFFu, pc[q]);
+    for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
+        const uint32_t w = pairs[2 * p + 1];
+        if (is_kill_i(w)) st.min_kill(w & 0xFFFFu, pairs[2 * p]);
+    }
+    __syncthreads();
+    int rounds = 0;
+    for (int round = 0; round <= nc; round++) {
+        for (int k = tid; k < nc; k += 1024) st.clear_pend(k);
+        __syncthreads();
+        // kills at the second end point happen only if c got past the first (:336-337)
+        {
+            uint32_t sq[LR_PR];
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++) sq[q] = (pc[q] != 0xFFFFFFFFu && is_kill_j(pw[q])) ? st.get_cst(pc[q]) : 0u;
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++) {
+                if (pc[q] == 0xFFFFFFFFu || !is_kill_j(pw[q])) continue;
+                if (sq[q] & CS_RI_KNOWN) { if (!(sq[q] & CS_RI)) st.min_kill(pw[q] & 0xFFFFu, pc[q]); }
+                else st.min_pend(pw[q] & 0xFFFFu, pc[q]);
+            }
+        }
+        for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
+            const uint32_t w = pairs[2 * p + 1];
+            if (!is_kill_j(w)) continue;
+            const uint32_t c = pairs[2 * p], s = st.get_cst(c);
+            if (s & CS_RI_KNOWN) { if (!(s & CS_RI)) st.min_kill(w & 0xFFFFu, c); }
+            else st.min_pend(w & 0xFFFFu, c);
+        }
+        __syncthreads();
+        // is the partner that would reject c alive when c arrives?
+        auto reject_bit = [&](uint32_t c, uint32_t w, uint32_t s, uint32_t sy, uint32_t kt, uint32_t pt) {
+            const uint32_t ep = (w >> 30) & 1u;
+            if (s & CS_ACC_KNOWN) return;
+            if (!ep && (s & CS_RI_KNOWN)) return;
+            if (((sy & CS_ACC_KNOWN) && !(sy & CS_ACC)) || kt < c) return;                      // dead or never listed
+            uint32_t bit;
+            if ((sy & CS_ACC_KNOWN) && pt > c) bit = ep ? CS_AJ_T : CS_AI_T;                   // alive
+            else bit = ep ? CS_AJ_U : CS_AI_U;                                                  // not settled yet
+            st.or_cst(c, bit);
+        };
+        {
+            uint32_t s_[LR_PR], sy_[LR_PR], kt_[LR_PR], pt_[LR_PR];
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++) {
+                const bool on = pc[q] != 0xFFFFFFFFu && !(pw[q] >> 31);
+                const uint32_t y = pw[q] & 0xFFFFu;
+                s_[q] = on ? st.get_cst(pc[q]) : CS_ACC_KNOWN;
+                sy_[q] = on ? st.get_cst(y) : 0u;
+                kt_[q] = on ? st.get_kill(y) : 0u;
+                pt_[q] = on ? st.get_pend(y) : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < LR_PR; q++)
+                if (pc[q] != 0xFFFFFFFFu && !(pw[q] >> 31)) reject_bit(pc[q], pw[q], s_[q], sy_[q], kt_[q], pt_[q]);
+        }
+        for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
+            const uint32_t w = pairs[2 * p + 1];
+            if (w >> 31) continue;
+            const uint32_t c = pairs[2 * p], y = w & 0xFFFFu;
+            reject_bit(c, w, st.get_cst(c), st.get_cst(y), st.get_kill(y), st.get_pend(y));
+        }
+        __syncthreads();
+        int open = 0;
+        for (int k = tid; k < nc; k += 1024) {
+            uint32_t s = st.get_cst(k);
+            if (s & CS_ACC_KNOWN) continue;
+            if (!(s & CS_RI_KNOWN)) {
+                if (s & CS_AI_T) s |= CS_RI_KNOWN | CS_RI | CS_ACC_KNOWN;        // rejected at i: never listed
+                else if (!(s & CS_AI_U)) s |= CS_RI_KNOWN;
+            }
+            if ((s & CS_RI_KNOWN) && !(s & CS_RI) && !(s & CS_ACC_KNOWN)) {
+                if (s & CS_AJ_T) s |= CS_ACC_KNOWN;
+                else if (!(s & CS_AJ_U)) s |= CS_ACC_KNOWN | CS_ACC;
+            }
+            s &= ~(CS_AI_T | CS_AI_U | CS_AJ_T | CS_AJ_U);
+            st.set_cst(k, s);
+            open += !(s & CS_ACC_KNOWN);
+        }
+        rounds = round + 1;
+        if (__syncthreads_count(open) == 0) break;
+    }
+    // the last round's second-end-point kills of candidates settled in that round
+    for (int p = tid; p < np; p += 1024) {
+        const uint32_t w = pairs[2 * p + 1];
+        if (!is_kill_j(w)) continue;
+        const uint32_t c = pairs[2 * p], s = st.get_cst(c);
+        if ((s & CS_RI_KNOWN) && !(s & CS_RI)) st.min_kill(w & 0xFFFFu, c);
+    }
+    __syncthreads();
+    return rounds;
+}
+
 __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
-    __shared__ int deg[LT_MAXPTS + 1];
-    __shared__ int cur[LT_MAXPTS + 1];
+    // one buffer: the relaxation's 16-bit arrays first, the per-point counters of the later phases afterwards
+    __shared__ __attribute__((aligned(16))) uint32_t lds_words[3 * LR_NC_LDS / 2];
+    static_assert(3 * LR_NC_LDS / 2 >= 2 * (LT_MAXPTS + 1), "deg and cur live in the same buffer");
+    int* deg = (int*)lds_words;
+    int* cur = deg + LT_MAXPTS + 1;
     __shared__ int part[1024];
     __shared__ int s_flag;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1907,120 +2069,23 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
     if (tid == 0) s_flag = 0;
 
     // ---- the sequential overlap pass as a relaxation ----
-    for (int k = tid; k < nc; k += 1024) {
-        uint32_t s = cst[k] & (CS_HAS_RI | CS_HAS_RJ);
-        if (!(s & CS_HAS_RI)) s |= CS_RI_KNOWN;                                    // nothing at i can reject it
-        if (!(s & (CS_HAS_RI | CS_HAS_RJ))) s |= CS_ACC_KNOWN | CS_ACC;
-        cst[k] = s;
-    }
-    // A thread's first LR_PR pairs stay in registers for all rounds, and every pass first issues all its loads and then
-    // works on the results: one work-group per frame makes this kernel a chain of memory latencies, and a pass that
-    // walks its pairs one by one pays two of them per pair.
-    constexpr int LR_PR = 8;
-    uint32_t pw[LR_PR], pc[LR_PR];
-#pragma unroll
-    for (int q = 0; q < LR_PR; q++) {
-        const int p = tid + 1024 * q;
-        pw[q] = p < np ? pairs[2 * p + 1] : 0u;
-        pc[q] = p < np ? pairs[2 * p] : 0xFFFFFFFFu;   // 0xFFFFFFFF: no pair
-    }
-    auto is_kill_i = [](uint32_t w) { return (w >> 31) && !((w >> 30) & 1u); };
-    auto is_kill_j = [](uint32_t w) { return (w >> 31) && ((w >> 30) & 1u); };
-#pragma unroll
-    for (int q = 0; q < LR_PR; q++)   // kills at the first end point are attempted whatever happens to c (:316-335)
-        if (pc[q] != 0xFFFFFFFFu && is_kill_i(pw[q])) atomicMin(&kill_t[pw[q] & 0xFFFFu], pc[q]);
-    for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
-        const uint32_t w = pairs[2 * p + 1];
-        if (is_kill_i(w)) atomicMin(&kill_t[w & 0xFFFFu], pairs[2 * p]);
-    }
-    __syncthreads();
-    for (int round = 0; round <= nc; round++) {
-        for (int k = tid; k < nc; k += 1024) pend_t[k] = LT_INF;
+    int rounds;
+    if (nc <= LR_NC_LDS) {
+        LrLds st;
+        st.cst = (uint16_t*)lds_words;
+        st.kill = st.cst + LR_NC_LDS;
+        st.pend = st.kill + LR_NC_LDS;
+        // the interaction kernel left the "something may reject it" bits in cst; every kill time starts at "never"
+        for (int k = tid; k < nc; k += 1024) { st.cst[k] = (uint16_t)cst[k]; st.kill[k] = 0xFFFFu; }
         __syncthreads();
-        // kills at the second end point happen only if c got past the first (:336-337)
-        {
-            uint32_t sq[LR_PR];
-#pragma unroll
-            for (int q = 0; q < LR_PR; q++) sq[q] = (pc[q] != 0xFFFFFFFFu && is_kill_j(pw[q])) ? cst[pc[q]] : 0u;
-#pragma unroll
-            for (int q = 0; q < LR_PR; q++) {
-                if (pc[q] == 0xFFFFFFFFu || !is_kill_j(pw[q])) continue;
-                if (sq[q] & CS_RI_KNOWN) { if (!(sq[q] & CS_RI)) atomicMin(&kill_t[pw[q] & 0xFFFFu], pc[q]); }
-                else atomicMin(&pend_t[pw[q] & 0xFFFFu], pc[q]);
-            }
-        }
-        for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
-            const uint32_t w = pairs[2 * p + 1];
-            if (!is_kill_j(w)) continue;
-            const uint32_t c = pairs[2 * p], s = cst[c];
-            if (s & CS_RI_KNOWN) { if (!(s & CS_RI)) atomicMin(&kill_t[w & 0xFFFFu], c); }
-            else atomicMin(&pend_t[w & 0xFFFFu], c);
-        }
+        rounds = line_relax(st, pairs, np, nc);
+        for (int k = tid; k < nc; k += 1024) { cst[k] = st.cst[k]; kill_t[k] = LrLds::widen(st.kill[k]); }
         __syncthreads();
-        // is the partner that would reject c alive when c arrives?
-        auto reject_bit = [&](uint32_t c, uint32_t w, uint32_t s, uint32_t sy, uint32_t kt, uint32_t pt) {
-            const uint32_t ep = (w >> 30) & 1u;
-            if (s & CS_ACC_KNOWN) return;
-            if (!ep && (s & CS_RI_KNOWN)) return;
-            if (((sy & CS_ACC_KNOWN) && !(sy & CS_ACC)) || kt < c) return;                      // dead or never listed
-            uint32_t bit;
-            if ((sy & CS_ACC_KNOWN) && pt > c) bit = ep ? CS_AJ_T : CS_AI_T;                   // alive
-            else bit = ep ? CS_AJ_U : CS_AI_U;                                                  // not settled yet
-            atomicOr(&cst[c], bit);
-        };
-        {
-            uint32_t s_[LR_PR], sy_[LR_PR], kt_[LR_PR], pt_[LR_PR];
-#pragma unroll
-            for (int q = 0; q < LR_PR; q++) {
-                const bool on = pc[q] != 0xFFFFFFFFu && !(pw[q] >> 31);
-                const uint32_t y = pw[q] & 0xFFFFu;
-                s_[q] = on ? cst[pc[q]] : CS_ACC_KNOWN;
-                sy_[q] = on ? cst[y] : 0u;
-                kt_[q] = on ? kill_t[y] : 0u;
-                pt_[q] = on ? pend_t[y] : 0u;
-            }
-#pragma unroll
-            for (int q = 0; q < LR_PR; q++)
-                if (pc[q] != 0xFFFFFFFFu && !(pw[q] >> 31)) reject_bit(pc[q], pw[q], s_[q], sy_[q], kt_[q], pt_[q]);
-        }
-        for (int p = tid + 1024 * LR_PR; p < np; p += 1024) {
-            const uint32_t w = pairs[2 * p + 1];
-            if (w >> 31) continue;
-            const uint32_t c = pairs[2 * p], y = w & 0xFFFFu;
-            reject_bit(c, w, cst[c], cst[y], kill_t[y], pend_t[y]);
-        }
-        __syncthreads();
-        int open = 0;
-        for (int k0 = tid; k0 < nc; k0 += 4 * 1024) {
-            uint32_t sv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) sv[u] = k0 + 1024 * u < nc ? cst[k0 + 1024 * u] : CS_ACC_KNOWN;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t s = sv[u];
-                if (s & CS_ACC_KNOWN) continue;
-                if (!(s & CS_RI_KNOWN)) {
-                    if (s & CS_AI_T) s |= CS_RI_KNOWN | CS_RI | CS_ACC_KNOWN;        // rejected at i: never listed
-                    else if (!(s & CS_AI_U)) s |= CS_RI_KNOWN;
-                }
-                if ((s & CS_RI_KNOWN) && !(s & CS_RI) && !(s & CS_ACC_KNOWN)) {
-                    if (s & CS_AJ_T) s |= CS_ACC_KNOWN;
-                    else if (!(s & CS_AJ_U)) s |= CS_ACC_KNOWN | CS_ACC;
-                }
-                s &= ~(CS_AI_T | CS_AI_U | CS_AJ_T | CS_AJ_U);
-                cst[k0 + 1024 * u] = s;
-                open += !(s & CS_ACC_KNOWN);
-            }
-        }
-        if (__syncthreads_count(open) == 0) { if (tid == 0) cnt[7] |= (round + 1) << 8; break; }
+    } else {
+        LrGlobal st{cst, kill_t, pend_t};
+        rounds = line_relax(st, pairs, np, nc);
     }
-    // the last round's second-end-point kills of candidates settled in that round
-    for (int p = tid; p < np; p += 1024) {
-        const uint32_t w = pairs[2 * p + 1];
-        if (!((w >> 31) && ((w >> 30) & 1u))) continue;
-        const uint32_t c = pairs[2 * p], s = cst[c];
-        if ((s & CS_RI_KNOWN) && !(s & CS_RI)) atomicMin(&kill_t[w & 0xFFFFu], c);
-    }
+    if (tid == 0) cnt[7] |= rounds << 8;
     for (int p = tid; p <= n; p += 1024) deg[p] = 0;
     __syncthreads();
 

@@ -191,6 +191,31 @@ def test_quarter_tiles_equal_big_tiles(pkg, synth, monkeypatch):
             big.close()
 
 
+def test_line_tail_large_candidate_lists(pkg, orc, synth):
+    """More line candidates than the relaxation's LDS arrays hold (20480; this frame has 21450): the device tail keeps its
+    state in global memory.
+    Edges, adjacency and collinearity lists against the oracle on the GPU's own tensors, and the frame must not have gone
+    to the host tail."""
+    H, W, maxnum = 1024, 1024, 1600
+    ctx = pkg.Context(pkg.default_config(W, H, max_batch=1, max_num=maxnum))
+    try:
+        img = synth.make_frame(H, W, 35, 0, "dense")
+        f0, h0 = ctx.tail_stats()
+        r = ctx.extract(img)
+        f1, h1 = ctx.tail_stats()
+        cfg = orc.default_cfg(W, H, maxnum)
+        kp = orc.detect_keypoints(cfg, ctx.read_tensor(pkg.T_SCORE))
+        assert r["n"] == kp["n"] == maxnum
+        refined = orc.refine_heat(cfg, ctx.read_tensor(pkg.T_HEAT))
+        ln = orc.detect_lines(cfg, refined, kp["un"], kp["out"])
+        assert np.array_equal(r["edge_idx"], ln["edge_idx"])
+        assert np.array_equal(r["conn_off"], ln["conn_off"]) and np.array_equal(r["conn_idx"], ln["conn_idx"])
+        assert np.array_equal(r["coline_off"], ln["coline_off"]) and np.array_equal(r["coline_pairs"], ln["coline_pairs"])
+        assert (f1 - f0, h1 - h0) == (1, 0), "the frame was handed to the host tail"
+    finally:
+        ctx.close()
+
+
 def test_batch_equals_single(pkg, synth):
     H, W = 96, 128
     imgs = [synth.make_frame(H, W, 40 + k, 0, "sparse" if k % 2 else "dense") for k in range(4)]
