@@ -2638,12 +2638,14 @@ hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
 //                          superset of the 16 columns that are nearest by the exact chain.  In fp16 the pass needs
 //                          1/16 of the matrix-core time of an fp32 MFMA; that time is what it takes from the
 //                          convolutions running beside it.
-//   match_exact_kernel     the exact chain for the listed columns only (about 10 per row), sorted: the same
-//                          eight-nearest lists match_topk_kernel makes from the full matrix
+//   match_exact_kernel     the exact chain for the listed columns only (about 23 per row), sorted by (distance,
+//                          column): up to the radius the list is complete for, the row's nearest-neighbour order
+//   desc_transpose_kernel  a column-major copy of B for the rows that have to be scanned whole
 //   match_jacobi_kernel    the sequential claim pass as a fixed point: given a guess of every row's match, each row
 //                          recomputes its own from the claims of the rows before it; the system is triangular, so
 //                          a guess that reproduces itself is the sequential result (rows 0..t-1 are final after
-//                          round t; in practice a handful of rounds).
+//                          round t; in practice a handful of rounds).  A row whose list runs dry is scanned whole
+//                          and keeps the columns up to its second-best free one as an extended list.
 // =====================================================================================
 constexpr int PF_ROWS = 32, PF_MAXCOLS = 1024, PF_LIST = 64;
 constexpr int PF_WAVES = 8, PF_THREADS = 64 * PF_WAVES, PF_Q = PF_MAXCOLS / 32 / PF_WAVES;   // column tiles per wave
