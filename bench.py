@@ -237,9 +237,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libppgfront has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PPG_BENCH_FORCE_DIST=1: set the process group up and run the barrier's collective in a world of one rank too
+    # (rehearsal of the multi-GPU code path on a one-GPU box, under the launcher the multi-GPU runs use)
+    force_dist = os.environ.get("PPG_BENCH_FORCE_DIST", "") not in ("", "0")
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if force_dist and "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = load_pkg()
     synth = importlib.import_module("ppg_slam_amd.synth")
@@ -257,7 +265,7 @@ def main():
             host[t, s] = synth.frame_from_scene(scene, H, W, t)
     frames = torch.from_numpy(host).cuda()
     streams_mod = importlib.import_module("ppg_slam_amd.streams")
-    shutter = streams_mod.ShutterBarrier(dist, "cuda")
+    shutter = streams_mod.ShutterBarrier(dist, "cuda", single_rank_too=force_dist)
 
     def barrier():
         torch.cuda.synchronize()

@@ -30,9 +30,10 @@ class ShutterBarrier:
     known to be released everywhere, which may lag by the collectives still in flight.  drain() waits for those.
     Every rank must call release() the same number of times (it is a collective); `count` tells how many were started."""
 
-    def __init__(self, dist, device, depth=8):
+    def __init__(self, dist, device, depth=8, single_rank_too=False):
         self.dist = dist
-        self.active = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        # a world of one needs no barrier; single_rank_too runs the collective anyway (rehearsal of the RCCL path on one GPU)
+        self.active = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_too)
         self.cuda = str(device).startswith("cuda")
         self.depth = depth
         self.count = 0
