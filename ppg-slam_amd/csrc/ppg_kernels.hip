@@ -1080,6 +1080,30 @@ __global__ __launch_bounds__(1024) void nms_emit_kernel(NmsArgs a) {
     __syncthreads();
     for (int k = m + tid; k < P; k += 1024) skey[k] = 0ull;
     __syncthreads();
+    if (P <= 1024) {
+        // one key per thread: the exchanges over fewer than 64 positions are lane shuffles, only the ten stages with
+        // a stride of 64 or more go through LDS (a sort of 1024 keys in LDS alone is 55 stages with a barrier each)
+        unsigned long long k = tid < P ? skey[tid] : 0ull;
+        for (int size = 2; size <= P; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                unsigned long long other;
+                if (stride < 64) {
+                    const unsigned lo32 = __shfl_xor((unsigned)(k & 0xFFFFFFFFull), stride);
+                    const unsigned hi32 = __shfl_xor((unsigned)(k >> 32), stride);
+                    other = ((unsigned long long)hi32 << 32) | lo32;
+                } else {
+                    __syncthreads();
+                    if (tid < P) skey[tid] = k;
+                    __syncthreads();
+                    other = tid < P ? skey[tid ^ stride] : 0ull;
+                }
+                const bool take_max = ((tid & stride) == 0) == ((tid & size) == 0);
+                k = take_max ? (k > other ? k : other) : (k < other ? k : other);
+            }
+        __syncthreads();
+        if (tid < P) skey[tid] = k;
+        __syncthreads();
+    } else
     // bitonic sort, descending
     for (int size = 2; size <= P; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
