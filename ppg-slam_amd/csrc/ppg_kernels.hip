@@ -2863,85 +2863,110 @@ __device__ inline float chain_distance2(const float* __restrict__ x, const float
 }
 __device__ inline float chain_distance(const float* __restrict__ x, const float* __restrict__ y) { return sqrtf(chain_distance2(x, y)); }
 
-// One wave per row: exact distances of the listed columns, sorted by (distance, column): near_idx/near_dist hold the
-// row's nearest columns in the order the reference's scan would rank them, near_len how many of them are certain
-// (nothing nearer is missing).  A row whose list overflowed is scanned completely (eight certain entries).
+// The listed columns of one row by W lanes (W = 64: a wave per row; W = 32: two rows per wave, for the usual lists of at
+// most 32 columns, so that half of the lanes do not idle through the 256-step chains): gl = lane inside the group.
+template <int W>
+__device__ inline void exact_listed(const PrefilterArgs& a, int b, int row, int cnt, int nB, int gl, int gshift,
+                                    int32_t* near_idx, float* near_dist, int* near_len) {
+    const float* x = a.A + b * a.sA + (size_t)row * 256;
+    const float* B = a.B + b * a.sB;
+    int32_t* oi = near_idx + ((size_t)b * a.maxn + row) * PF_NEAR;
+    float* od = near_dist + ((size_t)b * a.maxn + row) * PF_NEAR;
+    const float rad = a.list_rad[(size_t)b * a.maxn + row];
+    float d = 3e38f;
+    int p = 0x7FFFFFFF;
+    bool certain = false;
+    if (gl < cnt) {
+        p = a.list_col[((size_t)b * a.maxn + row) * PF_LIST + gl];
+        const float d2 = chain_distance2(x, B + (size_t)p * 256);
+        certain = d2 <= rad;
+        d = sqrtf(d2);
+    }
+    // rank of this lane's entry among the listed ones by (distance, column)
+    int rank = 0;
+    for (int o = 0; o < cnt; o++) {
+        const float od2 = __shfl(d, o, W);
+        const int op = __shfl(p, o, W);
+        rank += od2 < d || (od2 == d && op < p);
+    }
+    // entries are certain up to the first uncertain one in rank order
+    const unsigned long long unc = (__ballot(gl < cnt && !certain) >> gshift) & (W == 64 ? ~0ull : 0xFFFFFFFFull);
+    int first_unc = cnt;
+    for (int o = 0; o < cnt; o++) {
+        const int r = __shfl(rank, o, W);
+        if ((unc >> o) & 1ull) first_unc = min(first_unc, r);
+    }
+    // every column of the row is listed: the list is the whole row, certain to its end
+    const int len = cnt >= nB ? cnt : first_unc;
+    if (gl < cnt && rank < PF_NEAR) { oi[rank] = p; od[rank] = d; }
+    if (gl == 0) near_len[(size_t)b * a.maxn + row] = min(len, PF_NEAR);
+}
+
+// Exact distances of the listed columns, sorted by (distance, column): near_idx/near_dist hold the row's nearest
+// columns in the order the reference's scan would rank them, near_len how many of them are certain (nothing nearer is
+// missing).  A wave takes two rows; a row whose list overflowed is scanned completely (eight certain entries).
 __global__ __launch_bounds__(256) void match_exact_kernel(PrefilterArgs a, int32_t* near_idx, float* near_dist, int* near_len) {
     const int b = blockIdx.y;
     const int nA = a.nA_dev ? min(a.maxn, a.nA_dev[b * a.sn]) : a.nA, nB = a.nB_dev ? min(a.maxn, a.nB_dev[b * a.sn]) : a.nB;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= nA) return;
-    const float* x = a.A + b * a.sA + (size_t)row * 256;
-    const float* B = a.B + b * a.sB;
-    const int cnt = a.list_cnt[(size_t)b * a.maxn + row];
-    int32_t* oi = near_idx + ((size_t)b * a.maxn + row) * PF_NEAR;
-    float* od = near_dist + ((size_t)b * a.maxn + row) * PF_NEAR;
-    if (cnt <= PF_LIST) {
-        const float rad = a.list_rad[(size_t)b * a.maxn + row];
-        float d = 3e38f;
-        int p = 0x7FFFFFFF;
-        bool certain = false;
-        if (lane < cnt) {
-            p = a.list_col[((size_t)b * a.maxn + row) * PF_LIST + lane];
-            const float d2 = chain_distance2(x, B + (size_t)p * 256);
-            certain = d2 <= rad;
-            d = sqrtf(d2);
-        }
-        // rank of this lane's entry among the listed ones by (distance, column)
-        int rank = 0;
-        for (int o = 0; o < cnt; o++) {
-            const float od2 = __shfl(d, o);
-            const int op = __shfl(p, o);
-            rank += od2 < d || (od2 == d && op < p);
-        }
-        // entries are certain up to the first uncertain one in rank order
-        const unsigned long long unc = __ballot(lane < cnt && !certain);
-        int first_unc = cnt;
-        for (int o = 0; o < cnt; o++) {
-            const int r = __shfl(rank, o);
-            if ((unc >> o) & 1ull) first_unc = min(first_unc, r);
-        }
-        // every column of the row is listed: the list is the whole row, certain to its end
-        const int len = cnt >= nB ? cnt : first_unc;
-        if (lane < cnt && rank < PF_NEAR) { oi[rank] = p; od[rank] = d; }
-        if (lane == 0) near_len[(size_t)b * a.maxn + row] = min(len, PF_NEAR);
+    const int lane = threadIdx.x & 63;
+    const int row0 = 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row0 >= nA) return;
+    const int cnt0 = a.list_cnt[(size_t)b * a.maxn + row0];
+    const int cnt1 = row0 + 1 < nA ? a.list_cnt[(size_t)b * a.maxn + row0 + 1] : 0;
+    if (cnt0 <= 32 && cnt1 <= 32) {
+        const int h = lane >> 5;
+        // (both halves run the same code; the shuffles and the ballot slice stay inside a half)
+        const int row = row0 + h, cnt = h ? cnt1 : cnt0;
+        if (row < nA) exact_listed<32>(a, b, row, cnt, nB, lane & 31, 32 * h, near_idx, near_dist, near_len);
         return;
     }
-    float ld[TOPK];
-    int lp[TOPK];
+    for (int rr = 0; rr < 2; rr++) {
+        const int row = row0 + rr, cnt = rr ? cnt1 : cnt0;
+        if (row >= nA) break;
+        if (cnt <= PF_LIST) {
+            exact_listed<64>(a, b, row, cnt, nB, lane, 0, near_idx, near_dist, near_len);
+            continue;
+        }
+        const float* x = a.A + b * a.sA + (size_t)row * 256;
+        const float* B = a.B + b * a.sB;
+        int32_t* oi = near_idx + ((size_t)b * a.maxn + row) * PF_NEAR;
+        float* od = near_dist + ((size_t)b * a.maxn + row) * PF_NEAR;
+        float ld[TOPK];
+        int lp[TOPK];
 #pragma unroll
-    for (int t = 0; t < TOPK; t++) { ld[t] = 3e38f; lp[t] = 0x7FFFFFFF; }
-    for (int col = lane; col < nB; col += 64) {
-        float d = chain_distance(x, B + (size_t)col * 256);
-        int p = col;
+        for (int t = 0; t < TOPK; t++) { ld[t] = 3e38f; lp[t] = 0x7FFFFFFF; }
+        for (int col = lane; col < nB; col += 64) {
+            float d = chain_distance(x, B + (size_t)col * 256);
+            int p = col;
 #pragma unroll
-        for (int t = 0; t < TOPK; t++)
-            if (d < ld[t] || (d == ld[t] && p < lp[t])) {
-                const float td = ld[t]; const int tp = lp[t];
-                ld[t] = d; lp[t] = p; d = td; p = tp;
+            for (int t = 0; t < TOPK; t++)
+                if (d < ld[t] || (d == ld[t] && p < lp[t])) {
+                    const float td = ld[t]; const int tp = lp[t];
+                    ld[t] = d; lp[t] = p; d = td; p = tp;
+                }
+        }
+        int len = 0;
+        for (int t = 0; t < TOPK; t++) {
+            float d = ld[0];
+            int p = lp[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float od2 = __shfl_xor(d, o);
+                const int op = __shfl_xor(p, o);
+                if (od2 < d || (od2 == d && op < p)) { d = od2; p = op; }
             }
-    }
-    int len = 0;
-    for (int t = 0; t < TOPK; t++) {
-        float d = ld[0];
-        int p = lp[0];
+            if (lp[0] == p && p != 0x7FFFFFFF) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float od2 = __shfl_xor(d, o);
-            const int op = __shfl_xor(p, o);
-            if (od2 < d || (od2 == d && op < p)) { d = od2; p = op; }
+                for (int q = 0; q < TOPK - 1; q++) { ld[q] = ld[q + 1]; lp[q] = lp[q + 1]; }
+                ld[TOPK - 1] = 3e38f; lp[TOPK - 1] = 0x7FFFFFFF;
+            }
+            if (p != 0x7FFFFFFF) {
+                if (lane == 0) { od[t] = d; oi[t] = p; }
+                len = t + 1;
+            }
         }
-        if (lp[0] == p && p != 0x7FFFFFFF) {
-#pragma unroll
-            for (int q = 0; q < TOPK - 1; q++) { ld[q] = ld[q + 1]; lp[q] = lp[q + 1]; }
-            ld[TOPK - 1] = 3e38f; lp[TOPK - 1] = 0x7FFFFFFF;
-        }
-        if (p != 0x7FFFFFFF) {
-            if (lane == 0) { od[t] = d; oi[t] = p; }
-            len = t + 1;
-        }
+        if (lane == 0) near_len[(size_t)b * a.maxn + row] = len;
     }
-    if (lane == 0) near_len[(size_t)b * a.maxn + row] = len;
 }
 
 // Bt[b][d][col] = B[b][col][d]: the column-major copy the claim pass scans when a row needs all its distances (a thread
@@ -3205,7 +3230,7 @@ hipError_t launch_match_fused(const FusedMatchArgs& f, hipStream_t s) {
     hipLaunchKernelGGL(row_norm_kernel, gn, dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.maxn, f.sB, f.norm_work + (size_t)f.batch * f.maxn,
                        f.half_work + (size_t)f.batch * f.maxn * 256, f.nB);
     if (!(f.debug_skip & 4)) hipLaunchKernelGGL(match_prefilter_kernel, dim3((f.maxn + PF_ROWS - 1) / PF_ROWS, f.batch), dim3(PF_THREADS), 0, s, p);
-    if (!(f.debug_skip & 2)) hipLaunchKernelGGL(match_exact_kernel, gn, dim3(256), 0, s, p, f.near_idx, f.near_dist, f.near_len);
+    if (!(f.debug_skip & 2)) hipLaunchKernelGGL(match_exact_kernel, dim3((f.maxn + 7) / 8, f.batch), dim3(256), 0, s, p, f.near_idx, f.near_dist, f.near_len);
     if (f.debug_skip & 1) return hipGetLastError();
     hipLaunchKernelGGL(desc_transpose_kernel, dim3((f.maxn + 63) / 64, 4, f.batch), dim3(256), 0, s, f.B, f.nB_dev, f.sn, f.nB, f.maxn, f.sB, f.bt_work);
     JacobiArgs j;
