@@ -8,6 +8,7 @@
 
 #include <math.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace ppg {
 
@@ -46,64 +47,81 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
     for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int j = 0; j < 4; j++) biasv[n][j] = *(const f32x4*)(G.bias + cb + n * 32 + 8 * j + 4 * lh);
+    // one run of four couts: BN = the layer has a batch norm (al, be valid)
+    auto run = [&](auto BN, int n, int j, f32x4 bias, f32x4 al, f32x4 be) {
+        const int co = cb + n * 32 + 8 * j + 4 * lh;  // first of the four couts
+        if (co >= G.Cout) return;
+        if (G.mode == CONV_POOL2) {
+            // pooled layers use the 8 x 32 tile with two pixel tiles per wave (rows 2*wave, 2*wave+1 are the two
+            // tiles) or the 8 x 16 tile with one (the tile is two rows of 16: the row neighbour is lane ^ 16);
+            // the column neighbour is the next lane
+            if (!((MW == 32 && MT == 2) || (MW == 16 && MT == 1))) return;
+            const int y = y0 + 2 * wave, x = x0 + pcol(li);
+            f32x4 v;
 #pragma unroll
-    for (int n = 0; n < NT; n++) {
+            for (int e = 0; e < 4; e++) {
+                const float t = MT == 2 ? fmaxf(acc[0][n][4 * j + e], acc[MT - 1][n][4 * j + e])
+                                        : fmaxf(acc[0][n][4 * j + e], __shfl_xor(acc[0][n][4 * j + e], 16));
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+                float r = fmaxf(t, o) + bias[e];
+                if (G.relu) r = fmaxf(r, 0.f);
+                v[e] = r;
+            }
+            if ((li & 1) == 0 && (MT == 2 || li < 16) && y + 1 < a.H && x + 1 < a.W) {
+                float* dst = G.out + ((size_t)(b * (a.H / 2) + (y >> 1)) * (a.W / 2) + (x >> 1)) * G.Cout + co;
+                if (vec) *(f32x4*)dst = v;
+                else
+                    for (int e = 0; e < 4; e++)
+                        if (co + e < G.Cout) dst[e] = v[e];
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int co = cb + n * 32 + 8 * j + 4 * lh;  // first of the four couts
-            if (co >= G.Cout) continue;
-            const f32x4 bias = biasv[n][j];
-            f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-            if (bn) { al = *(const f32x4*)(G.alpha + co); be = *(const f32x4*)(G.beta + co); }
-            if (G.mode == CONV_POOL2) {
-                // pooled layers use the 8 x 32 tile with two pixel tiles per wave (rows 2*wave, 2*wave+1 are the two
-                // tiles) or the 8 x 16 tile with one (the tile is two rows of 16: the row neighbour is lane ^ 16);
-                // the column neighbour is the next lane
-                if (!((MW == 32 && MT == 2) || (MW == 16 && MT == 1))) continue;
-                const int y = y0 + 2 * wave, x = x0 + pcol(li);
+            for (int m = 0; m < MT; m++) {
+                const int y = y0 + prow(m, li), x = x0 + pcol(li);
+                if (y >= a.H || x >= a.W) continue;
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float t = MT == 2 ? fmaxf(acc[0][n][4 * j + e], acc[MT - 1][n][4 * j + e])
-                                            : fmaxf(acc[0][n][4 * j + e], __shfl_xor(acc[0][n][4 * j + e], 16));
-                    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));  // lane ^ 1
-                    float r = fmaxf(t, o) + bias[e];
+                    float r = acc[m][n][4 * j + e] + bias[e];
+                    if (BN) r = r * al[e] + be[e];
                     if (G.relu) r = fmaxf(r, 0.f);
                     v[e] = r;
                 }
-                if ((li & 1) == 0 && (MT == 2 || li < 16) && y + 1 < a.H && x + 1 < a.W) {
-                    float* dst = G.out + ((size_t)(b * (a.H / 2) + (y >> 1)) * (a.W / 2) + (x >> 1)) * G.Cout + co;
-                    if (vec) *(f32x4*)dst = v;
-                    else
-                        for (int e = 0; e < 4; e++)
-                            if (co + e < G.Cout) dst[e] = v[e];
+                float* dst;
+                if (G.mode == CONV_PLAIN) {
+                    dst = G.out + ((size_t)(b * a.H + y) * a.W + x) * G.Cout + co;
+                } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx; Cps is a multiple of 4
+                    const int q = co / Cps, cc = co - q * Cps;
+                    dst = G.out + ((size_t)(b * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1)) * Cps + cc;
                 }
-            } else {
-#pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    const int y = y0 + prow(m, li), x = x0 + pcol(li);
-                    if (y >= a.H || x >= a.W) continue;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float r = acc[m][n][4 * j + e] + bias[e];
-                        if (bn) r = r * al[e] + be[e];
-                        if (G.relu) r = fmaxf(r, 0.f);
-                        v[e] = r;
-                    }
-                    float* dst;
-                    if (G.mode == CONV_PLAIN) {
-                        dst = G.out + ((size_t)(b * a.H + y) * a.W + x) * G.Cout + co;
-                    } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx; Cps is a multiple of 4
-                        const int q = co / Cps, cc = co - q * Cps;
-                        dst = G.out + ((size_t)(b * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1)) * Cps + cc;
-                    }
-                    if (vec) *(f32x4*)dst = v;
-                    else
-                        for (int e = 0; e < 4; e++)
-                            if (co + e < G.Cout) dst[e] = v[e];
-                }
+                if (vec) *(f32x4*)dst = v;
+                else
+                    for (int e = 0; e < 4; e++)
+                        if (co + e < G.Cout) dst[e] = v[e];
             }
+        }
+    };
+    // No load may follow a store here: the counter a load is waited on counts the stores before it too, so a load
+    // in the middle of the epilogue waits out the full write latency of everything stored so far.  Without a batch norm
+    // there is none; with one (a single layer) its eight vectors per cout tile are fetched ahead of that tile's stores.
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    if (!bn) {
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) run(std::false_type{}, n, j, biasv[n][j], one, zero);
+    } else {
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            f32x4 al[4], be[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int co = min(cb + n * 32 + 8 * j + 4 * lh, G.Cout - 4);  // (runs past the layer are skipped below)
+                al[j] = *(const f32x4*)(G.alpha + co);
+                be[j] = *(const f32x4*)(G.beta + co);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) run(std::true_type{}, n, j, biasv[n][j], al[j], be[j]);
         }
     }
 }
@@ -139,6 +157,11 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
 // only 32 of the 64 couts of a packed weight block (NT = 1): a quarter of the work per work-group, for launches that
 // would otherwise leave most of the chip idle (one frame per call: 20 to 300 big tiles on 256 CUs).  The chain of
 // every output is the same in all shapes.
+#ifdef PPG_CONV_TIMING
+// microbenchmark builds only (tools/ubench/conv_bench.hip): per work-group ticks (10 ns) of prologue, main loop and
+// epilogue of the convolution kernels, summed, and the number of work-groups
+__device__ unsigned long long* g_conv_timing = nullptr;
+#endif
 template <int KS, int NT, int KC, bool FUSE1A = false, int MW = 32, int MT = 2, bool HALF = false>
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     static_assert(!HALF || NT == 1, "HALF takes one 32-cout tile out of a 64-cout block");
@@ -168,6 +191,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     float* w1s = patch + PH * PW;            // [9][64]
     float* b1s = w1s + 9 * 64;               // [64]
 
+#ifdef PPG_CONV_TIMING
+    const long long tm0 = wall_clock64();
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int bx = blockIdx.x;
     const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, b = bx / (a.tiles_x * a.tiles_y);
@@ -284,6 +310,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     fetch(0);
     stash();
     __syncthreads();
+#ifdef PPG_CONV_TIMING
+    const long long tm1 = wall_clock64();
+#endif
     const float* ins = smem;
     const float* ws = smem + IN_FLOATS_P;
     for (int c = 0; c < nchunks; c++) {
@@ -315,7 +344,19 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         __syncthreads();
     }
 
+#ifdef PPG_CONV_TIMING
+    const long long tm2 = wall_clock64();
+#endif
     conv_store<NT, MW, MT, HALF>(a, acc, wave, li, lh, x0, y0, b, nb);
+#ifdef PPG_CONV_TIMING
+    if (tid == 0 && g_conv_timing) {
+        const long long tm3 = wall_clock64();
+        atomicAdd(&g_conv_timing[0], (unsigned long long)(tm1 - tm0));
+        atomicAdd(&g_conv_timing[1], (unsigned long long)(tm2 - tm1));
+        atomicAdd(&g_conv_timing[2], (unsigned long long)(tm3 - tm2));
+        atomicAdd(&g_conv_timing[3], 1ull);
+    }
+#endif
 }
 
 // =====================================================================================
@@ -333,6 +374,12 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
 // 8-15.  LDS image of a pixel: [half 0: 8 hi | 8 lo][half 1: 8 hi | 8 lo] + 16 bytes of padding (80-byte stride: the
 // 16-byte fragment reads of 16 consecutive pixels fall on distinct banks); weights [tap][half][hi|lo][cout][8 bf16].
 // =====================================================================================
+// Timing experiments of tools/ubench/conv_bench.hip on conv_bf16_kernel (the results are wrong when any bit is set):
+// 1 / 2 = one LDS operand read serves both pixel tiles / both cout tiles, 4 = no hi/lo split arithmetic (the staged
+// registers go to LDS as they are), 8 = no input fetch after the first chunk.
+#ifndef PPG_EXP_LDS
+#define PPG_EXP_LDS 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -368,11 +415,6 @@ __device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, uns
 
 // KS = 1: a 1x1 layer has one tap per chunk, too little work between two barriers, so G chunks of 16 channels are staged
 // and consumed together (G = 2: 45 KiB of LDS).
-#ifdef PPG_CONV_TIMING
-// microbenchmark builds only (tools/ubench/conv_bench.hip): per work-group ticks (10 ns) of prologue, main loop and
-// epilogue of conv_bf16_kernel, summed, and the number of work-groups
-__device__ unsigned long long* g_conv_timing = nullptr;
-#endif
 template <int NT, bool FUSE1A, int MW, int TERMS, bool F16 = false, int KS = 3, int G = 1>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     static_assert(!FUSE1A || (KS == 3 && G == 1), "the fused first layer is 3x3");
@@ -456,8 +498,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
 #pragma unroll
             for (int k = 0; k < IN_PER_T; k++)
 #pragma unroll
-                for (int q = 0; q < 2; q++)
+                for (int q = 0; q < 2; q++) {
+                    if ((PPG_EXP_LDS & 8) && c) continue;
                     vin[k][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, gofs[k] + 16 * q, c * KC * 4, 0));
+                }
         } else {
             // conv1a + ReLU in fp32 for the slot's 8 channels (two quads), as in conv_mfma_kernel
             const int ch = c * KC + ((tid >> 2) & 1) * 8;
@@ -490,6 +534,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 unsigned h0, l0, h1, l1;
+#if PPG_EXP_LDS & 4
+                if (true) {
+                    h0 = __float_as_uint(vin[k][q][0]); l0 = __float_as_uint(vin[k][q][1]);
+                    h1 = __float_as_uint(vin[k][q][2]); l1 = __float_as_uint(vin[k][q][3]);
+                } else
+#endif
                 if (F16) {
                     split_f16(vin[k][q][0], vin[k][q][1], h0, l0, saturated);
                     split_f16(vin[k][q][2], vin[k][q][3], h1, l1, saturated);
@@ -537,12 +587,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
                 bf16x8 xh[2], xl[2], wh[NT], wl[NT];
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
+                    if ((PPG_EXP_LDS & 1) && m) { xh[m] = xh[0]; xl[m] = xl[0]; continue; }
                     const unsigned char* p = ins + ((prow(m, li) + ky) * IW + (pcol(li) + kx)) * PSTR + g * 64 + lh * 32;
                     xh[m] = *(const bf16x8*)p;
                     if (TERMS == 3) xl[m] = *(const bf16x8*)(p + 16);
                 }
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
+                    if ((PPG_EXP_LDS & 2) && n) { wh[n] = wh[0]; wl[n] = wl[0]; continue; }
                     const unsigned char* p = ws + ((((g * TAPS + tap) * 2 + lh) * 2) * NB + n * 32 + li) * 16;
                     wh[n] = *(const bf16x8*)p;
                     if (TERMS == 3) wl[n] = *(const bf16x8*)(p + NB * 16);
