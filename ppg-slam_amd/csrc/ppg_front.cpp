@@ -222,6 +222,10 @@ struct ppg_ctx {
     double* voc_weight = nullptr;
     DBuf<int32_t> bWord, bNode;
     DBuf<double> bWeight;
+    // Work-groups per cout block of the fused first / the other fp32 convolutions when a launch has at least twenty
+    // times as many tiles (each work-group then walks the tiles with that stride; 0 = one work-group per tile).
+    // PPG_CONV_PERSIST="f,o" overrides both.
+    int persist_fused = 0, persist_other = 0;
     bool no_quarter = false;    // PPG_NO_QUARTER_TILES=1: big convolution tiles whatever the batch size (read at ppg_create)
     bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
     int* mCount = nullptr;
@@ -653,6 +657,9 @@ void conv_tiling(const ppg_ctx* c, ppg::ConvArgs& a, const DevConv& dc, int mode
     a.mw = fused ? 32 : pick_tile(dc, H, W, mode);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
     a.quarter = 0;
+    // (only where every work-group gets the same number of tiles to within a few per cent)
+    a.persist = (fused ? c->persist_fused : c->persist_other);
+    if ((long)a.tiles_x * a.tiles_y * a.B < 20L * a.persist) a.persist = 0;
     if (c->no_quarter || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
     if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;
     a.quarter = 1;
@@ -833,6 +840,8 @@ static int create_impl(ppg_ctx* c) {
     HIPCHK(c, hipGetDeviceProperties(&prop, f.device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, PPG_EHIP, "device %d is %s; this library is built for gfx950 only", f.device_id, prop.gcnArchName);
+    // the fused first convolution keeps one work-group per resident slot (three per CU) walking the tiles
+    c->persist_fused = 3 * prop.multiProcessorCount;
     {
         const int rc0 = scratch_setup(c, f.device_id);
         if (rc0) return rc0;
@@ -855,6 +864,7 @@ static int create_impl(ppg_ctx* c) {
         c->dump_tail = getenv("PPG_DUMP_TAIL");
         const char* mm = getenv("PPG_MATCH_MATRIX");
         c->match_matrix = mm && atoi(mm) != 0;
+        if (const char* pe = getenv("PPG_CONV_PERSIST")) sscanf(pe, "%d,%d", &c->persist_fused, &c->persist_other);
         const char* nq = getenv("PPG_NO_QUARTER_TILES");
         c->no_quarter = nq && atoi(nq) != 0;
         const char* eh = getenv("PPG_EXTEND_HOST");

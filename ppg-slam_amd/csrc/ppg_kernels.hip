@@ -192,10 +192,21 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     float* b1s = w1s + 9 * 64;               // [64]
 
 #ifdef PPG_CONV_TIMING
-    const long long tm0 = wall_clock64();
+    long long tm0 = wall_clock64();
 #endif
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int bx = blockIdx.x;
+    if (FUSE1A) {  // conv1a's weights and bias stay in LDS for all tiles (the barrier after the patch load covers them)
+        for (int i = threadIdx.x; i < 9 * 64; i += 256) w1s[i] = a.w1a[i];
+        if (threadIdx.x < 64) b1s[threadIdx.x] = a.b1a[threadIdx.x];
+    }
+    for (int bx = blockIdx.x; bx < a.tiles_x * a.tiles_y * a.B; bx += gridDim.x) {
+    // (the thread index is made opaque per tile: otherwise every tile-invariant offset is hoisted out of the loop and
+    // held in registers through it, which spills)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+#ifdef PPG_CONV_TIMING
+    tm0 = wall_clock64();
+#endif
     const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, b = bx / (a.tiles_x * a.tiles_y);
     const int nb = blockIdx.y;
     const int x0 = tx * TW, y0 = ty * TH;
@@ -250,8 +261,6 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = (float)im[(size_t)gy * a.W + gx] / 255.0f;
             patch[i] = v;
         }
-        for (int i = tid; i < 9 * 64; i += 256) w1s[i] = a.w1a[i];
-        if (tid < 64) b1s[tid] = a.b1a[tid];
         __syncthreads();
     }
 
@@ -357,6 +366,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         atomicAdd(&g_conv_timing[3], 1ull);
     }
 #endif
+    }
 }
 
 // =====================================================================================
@@ -643,6 +653,8 @@ int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
 
 hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
     dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
+    // fp32 kernels: at most `persist` work-groups per cout block, each walking the tiles with that stride
+    if (a.persist > 0 && a.prec == 0 && (int)grid.x > a.persist) grid.x = a.persist;
     if (a.quarter) {
         // quarter-size work-groups: fp32 3x3 layers with 64-cout blocks only; tiles_x / tiles_y count 4 x 32 or 8 x 16 tiles
         if (ks != 3 || nt != 2 || a.img || a.prec != 0 || a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
