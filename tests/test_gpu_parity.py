@@ -191,6 +191,32 @@ def test_quarter_tiles_equal_big_tiles(pkg, synth, monkeypatch):
             big.close()
 
 
+def test_tile_walk_equals_one_group_per_tile(pkg, synth, monkeypatch):
+    """Large launches of the fused first convolution run a fixed number of work-groups that walk the tiles;
+    PPG_CONV_PERSIST="f,o" sets the number for the fused / the other fp32 layers, 0 = one work-group per tile.  Every network output must be bit-identical,
+    with tile counts that do and do not divide evenly, on even and on ragged sizes."""
+    for (H, W, n, walk) in ((480, 640, 2, "64,0"), (480, 640, 1, "7,5"), (120, 136, 3, "8,3"), (72, 104, 4, "1,1")):
+        imgs = [synth.make_frame(H, W, 710 + k, 0, "dense" if k % 2 else "sparse") for k in range(n)]
+        monkeypatch.setenv("PPG_NO_QUARTER_TILES", "1")
+        monkeypatch.setenv("PPG_CONV_PERSIST", "0,0")
+        plain = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500))
+        monkeypatch.setenv("PPG_CONV_PERSIST", walk)
+        walking = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500))
+        monkeypatch.delenv("PPG_CONV_PERSIST")
+        monkeypatch.delenv("PPG_NO_QUARTER_TILES")
+        try:
+            rp, rw = plain.extract_batch(imgs), walking.extract_batch(imgs)
+            for which in (pkg.T_FEAT, pkg.T_JUNC, pkg.T_HEAT_RAW, pkg.T_DESCMAP, pkg.T_SCORE, pkg.T_HEAT):
+                for f in range(n):
+                    assert np.array_equal(plain.read_tensor(which, f), walking.read_tensor(which, f)), (H, W, n, walk, which, f)
+            for a, b in zip(rp, rw):
+                assert np.array_equal(a["xy"], b["xy"]) and np.array_equal(a["desc"], b["desc"])
+                assert np.array_equal(a["edge_idx"], b["edge_idx"])
+        finally:
+            plain.close()
+            walking.close()
+
+
 def test_line_tail_large_candidate_lists(pkg, orc, synth):
     """More line candidates than the relaxation's LDS arrays hold (20480; this frame has 21450): the device tail keeps its
     state in global memory.
