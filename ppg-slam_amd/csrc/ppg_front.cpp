@@ -121,7 +121,9 @@ struct Lane {
     hipStream_t stream = nullptr;
     float *a1 = nullptr, *p1 = nullptr, *a2 = nullptr, *p2 = nullptr, *a3 = nullptr, *p3 = nullptr, *a4 = nullptr,
           *feat = nullptr, *pa_o = nullptr, *da_o = nullptr, *hs0 = nullptr, *hs1 = nullptr;
+    int* tile_ctr = nullptr;  // kTileCounters zeroed ints: hand-out counters of the convolutions that take several tiles per work-group
 };
+constexpr int kTileCounters = 256;
 
 }  // namespace
 
@@ -658,12 +660,14 @@ void conv_tiling(const ppg_ctx* c, ppg::ConvArgs& a, const DevConv& dc, int mode
     a.mw = fused ? 32 : pick_tile(dc, H, W, mode);
     a.tiles_x = (W + a.mw - 1) / a.mw; a.tiles_y = (H + 256 / a.mw - 1) / (256 / a.mw);
     a.quarter = 0;
-    // (only where every work-group gets the same number of tiles to within a few per cent)
+    // (only for launches of many tiles per work-group: shorter ones gain nothing from it)
     a.persist = (fused ? c->persist_fused : c->persist_other);
     if (!c->persist_forced && (long)a.tiles_x * a.tiles_y * a.B < 20L * a.persist) a.persist = 0;
+    a.tile_counter = c->lane[c->lane_cur].tile_ctr;
     if (c->no_quarter || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
     if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;
     a.quarter = 1;
+    if (4 * a.nblk > kTileCounters) a.persist = 0;  // (two counters per launched cout block, twice as many blocks)
     // pooling pairs the two rows of an 8 x 16 tile's pixel tiles; otherwise the shape with the least padded area
     const long a32 = (long)((H + 3) / 4 * 4) * ((W + 31) / 32 * 32), a16 = (long)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16);
     a.mw = (mode == ppg::CONV_POOL2 || a16 < a32) ? 16 : 32;
@@ -901,6 +905,8 @@ static int create_impl(ppg_ctx* c) {
         DL(da_o, B * hw * 256);
         DL(hs0, B * hw * 4 * 64);
         DL(hs1, B * hw * 16 * 16);
+        DL(tile_ctr, kTileCounters);
+        HIPCHK(c, hipMemset(l.tile_ctr, 0, kTileCounters * sizeof(int)));
 #undef DL
     }
     select_lane(c, 0);

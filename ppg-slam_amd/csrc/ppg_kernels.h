@@ -32,7 +32,8 @@ struct ConvArgs {
     int prec = 0;        // 0: fp32 MFMA; 1: bf16 hi/lo split, three products; 2: plain bf16; 3: fp16 hi/lo split (3x3, nt = 2 only)
     int B, H, W, Cin;
     int tiles_x, tiles_y, nblk;  // nblk = cout blocks of all groups together
-    int persist = 0;             // fp32 kernels: > 0 caps the work-groups per cout block (each then walks several tiles)
+    int persist = 0;             // fp32 kernels: > 0 caps the work-groups per cout block (each then takes several tiles)
+    int* tile_counter = nullptr; // 2 * nblk zeroed ints the tiles are handed out through when persist applies (the kernel zeroes them again)
     int mw = 32;         // tile shape: 32 -> 8 x 32 pixels, 16 -> 16 x 16 pixels (3x3, 64-cout blocks only)
     int quarter = 0;     // 1: quarter-size work-groups (fp32 3x3, 64-cout blocks): 4 x 32 (mw 32) or 8 x 16 (mw 16) pixels x 32 couts
     int ngroups = 1;

@@ -198,7 +198,22 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         for (int i = threadIdx.x; i < 9 * 64; i += 256) w1s[i] = a.w1a[i];
         if (threadIdx.x < 64) b1s[threadIdx.x] = a.b1a[threadIdx.x];
     }
-    for (int bx = blockIdx.x; bx < a.tiles_x * a.tiles_y * a.B; bx += gridDim.x) {
+    // A launch with fewer work-groups than tiles hands the tiles out through a counter (tile_counter[2 * cout block]):
+    // a work-group that becomes resident late, because another kernel held its slot, then simply takes fewer tiles.  The
+    // index of the next tile is fetched at the start of the current one.  The last work-group to run dry (counted in
+    // tile_counter[2 * cout block + 1]) puts both counters back to zero for the next launch.
+    __shared__ int next_tile;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    int* tctr = a.tile_counter ? a.tile_counter + 2 * blockIdx.y : nullptr;
+    int bx = blockIdx.x;
+    if (tctr) {
+        if (threadIdx.x == 0) next_tile = atomicAdd(tctr, 1);
+        __syncthreads();
+        bx = next_tile;
+    }
+    while (bx < ntiles) {
+    int fetched = ntiles;
+    if (tctr && threadIdx.x == 0) fetched = atomicAdd(tctr, 1);
     // (the thread index is made opaque per tile: otherwise every tile-invariant offset is hoisted out of the loop and
     // held in registers through it, which spills)
     int tid = threadIdx.x;
@@ -366,6 +381,17 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         atomicAdd(&g_conv_timing[3], 1ull);
     }
 #endif
+    if (tctr) {
+        if (threadIdx.x == 0) next_tile = fetched;
+        __syncthreads();
+        bx = next_tile;
+    } else {
+        bx += gridDim.x;
+    }
+    }
+    if (tctr && threadIdx.x == 0 && atomicAdd(tctr + 1, 1) == (int)gridDim.x - 1) {
+        atomicExch(tctr, 0);
+        atomicExch(tctr + 1, 0);
     }
 }
 
@@ -651,10 +677,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
 
 int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
 
-hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s) {
+hipError_t launch_conv(const ConvArgs& args, int ks, int nt, hipStream_t s) {
+    ConvArgs a = args;
     dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
     // fp32 kernels: at most `persist` work-groups per cout block, each walking the tiles with that stride
-    if (a.persist > 0 && a.prec == 0 && (int)grid.x > a.persist) grid.x = a.persist;
+    if (a.persist > 0 && a.prec == 0 && a.tile_counter && (int)grid.x > a.persist) grid.x = a.persist;
+    if ((int)grid.x == a.tiles_x * a.tiles_y * a.B) a.tile_counter = nullptr;  // one work-group per tile: no counter
     if (a.quarter) {
         // quarter-size work-groups: fp32 3x3 layers with 64-cout blocks only; tiles_x / tiles_y count 4 x 32 or 8 x 16 tiles
         if (ks != 3 || nt != 2 || a.img || a.prec != 0 || a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;

@@ -192,7 +192,8 @@ def test_quarter_tiles_equal_big_tiles(pkg, synth, monkeypatch):
 
 
 def test_tile_walk_equals_one_group_per_tile(pkg, synth, monkeypatch):
-    """Large launches of the fused first convolution run a fixed number of work-groups that walk the tiles;
+    """Large launches of the fused first convolution run a fixed number of work-groups that take their tiles from a counter
+    (which the kernel leaves at zero for the next launch: every context below extracts twice);
     PPG_CONV_PERSIST="f,o" sets the number for the fused / the other fp32 layers, 0 = one work-group per tile.  Every network output must be bit-identical,
     with tile counts that do and do not divide evenly, on even and on ragged sizes."""
     for (H, W, n, walk) in ((480, 640, 2, "64,0"), (480, 640, 1, "7,5"), (120, 136, 3, "8,3"), (72, 104, 4, "1,1")):
@@ -205,6 +206,7 @@ def test_tile_walk_equals_one_group_per_tile(pkg, synth, monkeypatch):
         monkeypatch.delenv("PPG_CONV_PERSIST")
         monkeypatch.delenv("PPG_NO_QUARTER_TILES")
         try:
+            walking.extract_batch(imgs[::-1])
             rp, rw = plain.extract_batch(imgs), walking.extract_batch(imgs)
             for which in (pkg.T_FEAT, pkg.T_JUNC, pkg.T_HEAT_RAW, pkg.T_DESCMAP, pkg.T_SCORE, pkg.T_HEAT):
                 for f in range(n):
