@@ -273,6 +273,21 @@ def test_bench_batch_equals_single_vga(pkg, synth):
             assert np.array_equal(rs[k][key], s[key], equal_nan=True), (k, key)
 
 
+def test_repeated_bench_batches_are_idempotent(pkg, synth):
+    """Forty extractions of two alternating 16-frame VGA batches through one context (the size at which the fused first
+    convolution hands its tiles out through a counter that every launch must leave at zero): each result equals the
+    first one of its batch."""
+    H, W, B = 480, 640, 16
+    sets = [[synth.make_frame(H, W, 900 + 16 * s + k, k % 3, "dense" if k % 2 else "sparse") for k in range(B)] for s in range(2)]
+    ctx = get_ctx(pkg, W, H, 1024, batch=B)
+    first = [ctx.extract_batch(imgs) for imgs in sets]
+    for rep in range(38):
+        rs = ctx.extract_batch(sets[rep % 2])
+        for k in (0, 5, 15):
+            for key in ("xy", "desc", "edge_idx"):
+                assert np.array_equal(rs[k][key], first[rep % 2][k][key]), (rep, k, key)
+
+
 def test_degenerate_frames(pkg):
     H, W = 64, 96
     ctx = get_ctx(pkg, W, H)
