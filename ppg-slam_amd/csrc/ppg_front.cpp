@@ -208,7 +208,8 @@ struct ppg_ctx {
     DBuf<float> mA, mB, mD, mBest, mSecond, mTopD;
     DBuf<int32_t> mOff, mIdx, mMatch, mTopI;
     DBuf<uint8_t> mSkip, mSkipOut, mRowClaims, xArena;
-    std::vector<uint8_t> xHost;      // host image of xArena (ppg_extend_map_matches)
+    uint8_t* xPin = nullptr;         // pinned host image of xArena (ppg_extend_map_matches)
+    size_t xPinCap = 0;
     bool extend_on_host = false;     // PPG_EXTEND_HOST=1: the host walk (the statement the device walk is checked against)
     DBuf<uint32_t> mClaim;
     DBuf<float> mNorm;
@@ -798,6 +799,7 @@ void ppg_destroy(ppg_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (void* p : c->dev_allocs) (void)hipFree(p);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
+    if (c->xPin) (void)hipHostFree(c->xPin);
     void* ms[] = {c->mA.p, c->mB.p, c->mD.p, c->mBest.p, c->mSecond.p, c->mTopD.p, c->mOff.p,
                   c->mIdx.p, c->mMatch.p, c->mTopI.p, c->mSkip.p, c->mClaim.p, c->mNorm.p, c->mListCnt.p, c->mListCol.p, c->mHalf.p, c->mBt.p, c->mExt.p, c->mNearLen.p, c->mListRad.p, c->bWord.p, c->bNode.p, c->bWeight.p, c->mSkipOut.p, c->mRowClaims.p, c->xArena.p,
                   c->voc_desc, c->voc_child_off, c->voc_child_idx, c->voc_word, c->voc_weight};
@@ -2281,42 +2283,63 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
     }
     ppg_grid_free(grid);
     const size_t nw = widx.size(), ne = (size_t)g->edge_off[m], nconn = (size_t)conn_off[n];
-    // one packed upload: every array at a 256-byte aligned offset of one host block
+    // what the walk reads of the two graphs, flattened once: per map point its flags, per map edge the point at its
+    // usable other end (:298-304), per listed key edge the key point at its other end (KeyEdge::theOtherPid)
+    std::vector<uint8_t> flags(m);
+    for (int i = 0; i < m; i++) flags[i] = (uint8_t)((tracked[i] ? 1 : 0) | (g->bad[i] ? 2 : 0) | (g->nobs[i] > 0 ? 4 : 0));
+    std::vector<int32_t> eusable(ne), cother(nconn);
+    for (size_t k = 0; k < ne; k++) eusable[k] = g->edge_ok[k] && g->edge_other[k] >= 0 ? g->edge_other[k] : -1;
+    for (int i = 0; i < n; i++)
+        for (int k = conn_off[i]; k < conn_off[i + 1]; k++) {
+            const uint32_t e = conn_idx[k];
+            cother[k] = (int32_t)(edge_idx[2 * e] == (uint32_t)i ? edge_idx[2 * e + 1] : edge_idx[2 * e]);
+        }
+    // one packed upload from pinned memory: every array at a 256-byte aligned offset of one block; the arrays that come
+    // back (F.mvpMapPoints, F.mvpMapEdges, the tracked flags, the counters) lie together at its end
     struct Part { const void* src; size_t bytes; size_t off; };
     std::vector<Part> parts;
     size_t total = 0;
     auto add = [&](const void* src, size_t bytes) { parts.push_back({src, bytes, total}); total += (bytes + 255) / 256 * 256; return parts.size() - 1; };
     const size_t iMdesc = add(g->desc, sizeof(float) * 256 * m), iFdesc = add(desc, sizeof(float) * 256 * n);
     const size_t iCands = add(cands.data(), sizeof(int32_t) * ncand), iWoff = add(woff.data(), sizeof(int32_t) * (ncand + 1));
-    const size_t iWidx = add(widx.data(), sizeof(int32_t) * nw), iBad = add(g->bad, m), iNobs = add(g->nobs, sizeof(int32_t) * m);
+    const size_t iWidx = add(widx.data(), sizeof(int32_t) * nw), iFlags = add(flags.data(), m);
     const size_t iEoff = add(g->edge_off, sizeof(int32_t) * (m + 1)), iEid = add(g->edge_id, sizeof(int32_t) * ne);
-    const size_t iEoth = add(g->edge_other, sizeof(int32_t) * ne), iEok = add(g->edge_ok, ne);
-    const size_t iKe = add(edge_idx, sizeof(uint32_t) * 2 * n_edges), iCoff = add(conn_off, sizeof(int32_t) * (n + 1));
-    const size_t iCidx = add(conn_idx, sizeof(uint32_t) * nconn), iTr = add(tracked, m), iFmp = add(frame_mp, sizeof(int32_t) * n);
+    const size_t iEus = add(eusable.data(), sizeof(int32_t) * ne), iCoff = add(conn_off, sizeof(int32_t) * (n + 1));
+    const size_t iCidx = add(conn_idx, sizeof(uint32_t) * nconn), iCoth = add(cother.data(), sizeof(int32_t) * nconn);
+    const size_t iFmp = add(frame_mp, sizeof(int32_t) * n);
     const size_t iFme = add(frame_me, frame_me ? sizeof(int32_t) * n_edges : 0);
-    const size_t oWdist = total; total += (sizeof(float) * nw + 255) / 256 * 256;
+    const size_t oUp = total;                                  // end of the upload
+    const size_t oTr = total; total += ((size_t)m + 255) / 256 * 256;
     const size_t oOut = total; total += 256;
+    const size_t oBack = parts[iFmp].off, nBack = total - oBack;   // what comes back
+    const size_t oWdist = total; total += (sizeof(float) * nw + 255) / 256 * 256;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     int rc = grow(c, c->xArena, total);
     if (rc) return rc;
-    c->xHost.resize(total);
+    if (c->xPinCap < oWdist) {
+        if (c->xPin) HIPCHK(c, hipHostFree(c->xPin));
+        c->xPin = nullptr; c->xPinCap = 0;
+        void* q = nullptr;
+        HIPCHK(c, hipHostMalloc(&q, oWdist + oWdist / 2, hipHostMallocDefault));
+        c->xPin = (uint8_t*)q; c->xPinCap = oWdist + oWdist / 2;
+    }
     for (const Part& p : parts)
-        if (p.bytes) memcpy(c->xHost.data() + p.off, p.src, p.bytes);
+        if (p.bytes) memcpy(c->xPin + p.off, p.src, p.bytes);
     hipStream_t s = c->post;
     HIPCHK(c, hipStreamSynchronize(c->match_stream));   // a pipelined match may still be using the work arrays below
     uint8_t* base = c->xArena.p;
-    HIPCHK(c, hipMemcpyAsync(base, c->xHost.data(), oWdist, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(base, c->xPin, oUp, hipMemcpyHostToDevice, s));
     auto dp = [&](size_t i) { return base + parts[i].off; };
     HIPCHK(c, ppg::launch_dist_csr_rows((const float*)dp(iMdesc), (const int32_t*)dp(iCands), ncand, (const float*)dp(iFdesc),
                                         (const int32_t*)dp(iWoff), (const int32_t*)dp(iWidx), (float*)(base + oWdist), s));
     ppg::ExtendArgs x;
-    x.m = m; x.n = n; x.n_edges = n_edges; x.ncand = ncand;
+    x.m = m; x.n = n; x.n_edges = n_edges; x.ncand = ncand; x.n_map_edges = (int)ne; x.n_conn = (int)nconn;
     x.cands = (const int32_t*)dp(iCands); x.win_off = (const int32_t*)dp(iWoff); x.win_idx = (const int32_t*)dp(iWidx);
     x.win_dist = (const float*)(base + oWdist); x.mdesc = (const float*)dp(iMdesc); x.fdesc = (const float*)dp(iFdesc);
-    x.bad = (const uint8_t*)dp(iBad); x.nobs = (const int32_t*)dp(iNobs); x.edge_off = (const int32_t*)dp(iEoff);
-    x.edge_id = (const int32_t*)dp(iEid); x.edge_other = (const int32_t*)dp(iEoth); x.edge_ok = (const uint8_t*)dp(iEok);
-    x.key_edge_idx = (const uint32_t*)dp(iKe); x.conn_off = (const int32_t*)dp(iCoff); x.conn_idx = (const uint32_t*)dp(iCidx);
-    x.tracked = (uint8_t*)dp(iTr); x.frame_mp = (int32_t*)dp(iFmp); x.frame_me = frame_me ? (int32_t*)dp(iFme) : nullptr;
+    x.flags = (const uint8_t*)dp(iFlags); x.edge_off = (const int32_t*)dp(iEoff); x.edge_id = (const int32_t*)dp(iEid);
+    x.edge_usable = (const int32_t*)dp(iEus); x.conn_off = (const int32_t*)dp(iCoff); x.conn_idx = (const uint32_t*)dp(iCidx);
+    x.conn_other = (const int32_t*)dp(iCoth);
+    x.tracked = base + oTr; x.frame_mp = (int32_t*)dp(iFmp); x.frame_me = frame_me ? (int32_t*)dp(iFme) : nullptr;
     x.nnratio = nnratio; x.out = (int*)(base + oOut);
     if ((size_t)m * n <= ((size_t)1 << 24)) {
         // every weight a seed can ask for, evaluated in parallel up front (it stays on the device): the walk then looks a
@@ -2327,19 +2350,16 @@ int ppg_extend_map_matches(ppg_ctx* c, float nnratio, float th, const ppg_mapgra
         x.Dfull = c->mD.p;
     }
     HIPCHK(c, ppg::launch_extend_map_matches(x, s));
-    // results land in the host block first: a walk that exceeded the kernel's limits is redone on the host from the
+    // results land in the pinned block first: a walk that exceeded the kernel's limits is redone on the host from the
     // caller's untouched arrays
-    HIPCHK(c, hipMemcpyAsync(c->xHost.data() + parts[iTr].off, dp(iTr), m, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->xHost.data() + parts[iFmp].off, dp(iFmp), sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-    if (frame_me && n_edges) HIPCHK(c, hipMemcpyAsync(c->xHost.data() + parts[iFme].off, dp(iFme), sizeof(int32_t) * n_edges, hipMemcpyDeviceToHost, s));
-    int out[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(out, base + oOut, sizeof(out), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->xPin + oBack, base + oBack, nBack, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    const int* out = (const int*)(c->xPin + oOut);
     if (out[1])
         return extend_map_matches_host(c, nnratio, th, g, desc, pos_un, n, edge_idx, n_edges, conn_off, conn_idx, tracked, frame_mp, frame_me, n_matches);
-    memcpy(tracked, c->xHost.data() + parts[iTr].off, m);
-    memcpy(frame_mp, c->xHost.data() + parts[iFmp].off, sizeof(int32_t) * n);
-    if (frame_me && n_edges) memcpy(frame_me, c->xHost.data() + parts[iFme].off, sizeof(int32_t) * n_edges);
+    memcpy(tracked, c->xPin + oTr, m);
+    memcpy(frame_mp, c->xPin + parts[iFmp].off, sizeof(int32_t) * n);
+    if (frame_me && n_edges) memcpy(frame_me, c->xPin + parts[iFme].off, sizeof(int32_t) * n_edges);
     if (n_matches) *n_matches = out[0];
     return PPG_OK;
 }

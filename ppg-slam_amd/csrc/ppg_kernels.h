@@ -251,8 +251,11 @@ struct ProjMatchArgs {
 hipError_t launch_match_projected(const ProjMatchArgs& a, hipStream_t s);
 
 // ---- Matcher::ExtendMapMatches on the device ----
+// Every array below starts on a 16-byte boundary and is readable up to the next multiple of 16 bytes (the kernel
+// fetches them sixteen bytes per lane).
 struct ExtendArgs {
     int m, n, n_edges, ncand;
+    int n_map_edges, n_conn;       // lengths of edge_usable / edge_id and of conn_other / conn_idx
     const int32_t* cands;          // trackable map points in visiting order (sorted by edge count on the host)
     const int32_t* win_off;        // [ncand + 1] window of every candidate: key points in GetFeaturesInArea order
     const int32_t* win_idx;
@@ -260,20 +263,18 @@ struct ExtendArgs {
     const float* mdesc;            // [m][256]
     const float* fdesc;            // [n][256]
     const float* Dfull = nullptr;  // optional [m][n] distance matrix (same chain): seed weights are looked up instead of evaluated
-    const uint8_t* bad;            // [m]
-    const int32_t* nobs;           // [m]
+    const uint8_t* flags;          // [m] bit 0 tracked already, bit 1 isBad(), bit 2 nObs > 0
     const int32_t* edge_off;       // [m + 1] map edges per point
     const int32_t* edge_id;
-    const int32_t* edge_other;
-    const uint8_t* edge_ok;
-    const uint32_t* key_edge_idx;  // [n_edges][2]
-    const int32_t* conn_off;       // [n + 1]
-    const uint32_t* conn_idx;
-    uint8_t* tracked;              // [m] in/out
+    const int32_t* edge_usable;    // per map edge: the point at its other end, -1 when the edge is bad or that point is missing
+    const int32_t* conn_off;       // [n + 1] key edges per key point
+    const uint32_t* conn_idx;      // their ids
+    const int32_t* conn_other;     // and the key point at the other end of each
+    uint8_t* tracked;              // [m] out
     int32_t* frame_mp;             // [n] in/out
     int32_t* frame_me;             // [n_edges] in/out or nullptr
     float nnratio;
-    int* out;                      // [0] the reference's return value, [1] set when a degree exceeded the kernel's limits
+    int* out;                      // [0] the reference's return value, [1] set when a list exceeded the kernel's limits
 };
 hipError_t launch_extend_map_matches(const ExtendArgs& a, hipStream_t s);
 hipError_t launch_dist_csr_rows(const float* A, const int32_t* rows, int nrows, const float* B, const int32_t* cand_off,

@@ -3453,111 +3453,206 @@ hipError_t launch_match_projected(const ProjMatchArgs& a, hipStream_t s) {
 //
 // The loop is sequential by nature: every accepted map point changes F.mvpMapPoints, which the skip rule of the next
 // window search reads (:253-255), and the seed growing (:287-377) walks the two graphs breadth first, assigning as it
-// goes.  The distances of the window searches do not depend on that state and arrive precomputed (one parallel
-// launch over all windows); the weights of a seed's small (map edges) x (key edges) matrix are evaluated when the
-// seed is popped, a lane per pair.  Mutable state lives in LDS: tracked flags, F.mvpMapPoints and the seed queue (every
-// push marks another map point tracked, so one walk never pushes more than m entries).
+// goes.  What bounds such a walk is the chain of dependent memory accesses, so nothing the walk decides on is fetched
+// from global memory inside it: the flags of the map points (tracked / bad / observed), F.mvpMapPoints, both adjacency
+// structures (for every listed edge the point at its other end) and the seed queue live in LDS; the per-candidate
+// scalars (map point, window range, edge range) are fetched 64 candidates at a time, a lane each, and read back by
+// lane index; a candidate's window (indices and precomputed distances) is fetched while the candidate before it is
+// processed.  What remains is one global access per popped seed: the weights of its (map edges) x (key edges)
+// matrix, a lane per pair, looked up in the distance matrix.  Minima over the wave go through DPP row shifts.
 // =====================================================================================
-constexpr int EX_MAXM = 8192, EX_MAXN = 4096, EX_MAXDEG = 64, EX_MAXW = 1024;
+constexpr int EX_MAXM = 8192, EX_MAXN = 4096, EX_MAXDEG = 64, EX_MAXW = 1024, EX_MAXCONN = 16384, EX_MAXME = 16384;
+
+// minimum over the 64 lanes (result uniform): inclusive scan inside each row of 16 lanes by row shifts, then the row
+// totals carried over by the two row broadcasts; lane 63 ends up with the minimum of the wave
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+#define PPG_DPP_MIN(ctrl, rowmask) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rowmask, 0xf, false))
+    PPG_DPP_MIN(0x111, 0xf);   // row_shr:1
+    PPG_DPP_MIN(0x112, 0xf);   // row_shr:2
+    PPG_DPP_MIN(0x114, 0xf);   // row_shr:4
+    PPG_DPP_MIN(0x118, 0xf);   // row_shr:8
+    PPG_DPP_MIN(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    PPG_DPP_MIN(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef PPG_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// sixteen bytes per lane from a padded global array into a narrower LDS array
+template <class D>
+__device__ inline void ex_fill_i32(D* dst, const int32_t* __restrict__ src, int count, int lane) {
+#pragma unroll 4
+    for (int k = lane * 4; k < count; k += 256) {
+        const int4 v = *reinterpret_cast<const int4*>(src + k);
+        dst[k] = (D)v.x;
+        if (k + 1 < count) dst[k + 1] = (D)v.y;
+        if (k + 2 < count) dst[k + 2] = (D)v.z;
+        if (k + 3 < count) dst[k + 3] = (D)v.w;
+    }
+}
 
 __global__ __launch_bounds__(64) void extend_map_matches_kernel(ExtendArgs a) {
-    __shared__ uint8_t tracked[EX_MAXM];
-    __shared__ int32_t fmp[EX_MAXN];
+    __shared__ uint8_t flags[EX_MAXM];            // bit 0 tracked, bit 1 bad, bit 2 observed
+    __shared__ int16_t fmp[EX_MAXN];              // F.mvpMapPoints as map point ids (m <= 8192), -1 = none
+    __shared__ uint16_t queue[EX_MAXM + 1];       // every push marks another map point tracked: at most m pushes per walk
     __shared__ float W[EX_MAXW];
-    __shared__ uint16_t queue[EX_MAXM + 1];
-    __shared__ uint8_t lxs[EX_MAXDEG], rowused[EX_MAXDEG], colused[EX_MAXDEG];
+    __shared__ int32_t coff[EX_MAXN + 1];
+    __shared__ uint16_t cother[EX_MAXCONN];
+    __shared__ int16_t eother[EX_MAXME];
+    __shared__ int16_t rowmp[EX_MAXDEG];
+    __shared__ uint8_t lxs[EX_MAXDEG];
     const int lane = threadIdx.x;
     const float TH_HIGH = 0.8f;   // matching/src/Matcher.cpp:12
-    for (int k = lane; k < a.m; k += 64) tracked[k] = a.tracked[k];
-    for (int k = lane; k < a.n; k += 64) fmp[k] = a.frame_mp[k];
+    if (a.n_conn > EX_MAXCONN || a.n_map_edges > EX_MAXME) {   // (uniform)
+        if (lane == 0) { a.out[0] = 0; a.out[1] = 1; }
+        return;
+    }
+#pragma unroll 2
+    for (int k = lane * 4; k < a.m; k += 256) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(a.flags + k);
+        flags[k] = v.x;
+        if (k + 1 < a.m) flags[k + 1] = v.y;
+        if (k + 2 < a.m) flags[k + 2] = v.z;
+        if (k + 3 < a.m) flags[k + 3] = v.w;
+    }
+    ex_fill_i32(fmp, a.frame_mp, a.n, lane);
+    ex_fill_i32(coff, a.conn_off, a.n + 1, lane);
+    ex_fill_i32(cother, a.conn_other, a.n_conn, lane);
+    ex_fill_i32(eother, a.edge_usable, a.n_map_edges, lane);
     __syncthreads();
     int nmatches = 0;
     bool overflow = false;
-    for (int c = 0; c < a.ncand && !overflow; c++) {
-        const int mp = a.cands[c];
-        if (tracked[mp] || a.bad[mp]) continue;                                   // :227
-        const int w0 = a.win_off[c], cnt = a.win_off[c + 1] - w0;
-        if (cnt == 0) continue;
-        Best2 v = {1e6f, 1e6f, -1, -1};
-        for (int k = lane; k < cnt; k += 64) {                                    // :251-270
-            const int id = a.win_idx[w0 + k];
-            const int cur = fmp[id];
-            if (cur >= 0 && a.nobs[cur] > 0) continue;
-            const float d = a.win_dist[w0 + k];
-            if (d < v.b) { v.b2 = v.b; v.b = d; v.pos = k; v.idx = id; }
-            else if (d < v.b2) v.b2 = d;
+    for (int c0 = 0; c0 < a.ncand && !overflow; c0 += 64) {
+        // the scalars of 64 candidates, a lane each
+        const int cl = min(c0 + lane, a.ncand - 1);
+        const int my_mp = a.cands[cl];
+        const int my_w0 = a.win_off[cl], my_w1 = a.win_off[cl + 1];
+        const int my_e0 = a.edge_off[my_mp], my_e1 = a.edge_off[my_mp + 1];
+        const int nchunk = min(64, a.ncand - c0);
+        int nx_id = 0;
+        float nx_d = 0.f;
+        {
+            const int w0 = __builtin_amdgcn_readlane(my_w0, 0), w1 = __builtin_amdgcn_readlane(my_w1, 0);
+            if (lane < w1 - w0) { nx_id = a.win_idx[w0 + lane]; nx_d = a.win_dist[w0 + lane]; }
         }
-        v = best2_wave(v);
-        if (v.b > TH_HIGH && v.b > a.nnratio * v.b2) continue;                    // :276
-        if (v.idx < 0) continue;   // every candidate of the window was skipped (the reference would index with -1, :279)
-        if (lane == 0) { fmp[v.idx] = mp; tracked[mp] = 1; queue[0] = (uint16_t)v.idx; }
-        nmatches++;
-        __syncthreads();
-        int qh = 0, qt = 1;
-        const int me0 = a.edge_off[mp], nme = a.edge_off[mp + 1] - me0;          // the map side stays the first seed's point (:296)
-        while (qh < qt) {
-            const int keyID = queue[qh];
-            qh++;
-            const int ke0 = a.conn_off[keyID], nke = a.conn_off[keyID + 1] - ke0;
-            if (nme == 0 || nke == 0) continue;
-            if (nme > EX_MAXDEG || nke > EX_MAXDEG) { overflow = true; break; }
-            // lx: the map edges that are usable, in order
-            const bool okrow = lane < nme && a.edge_ok[me0 + lane] && a.edge_other[me0 + lane] >= 0;
-            const unsigned long long mrow = __ballot(okrow);
-            const int nlx = __popcll(mrow);
-            if (okrow) lxs[__popcll(mrow & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-            if (lane < EX_MAXDEG) { rowused[lane] = 0; colused[lane] = 0; }
-            const int P = nlx * nke;
-            if (P > EX_MAXW) { overflow = true; break; }
-            __syncthreads();
-            auto key_other = [&](uint32_t e) { return a.key_edge_idx[2 * e] == (uint32_t)keyID ? a.key_edge_idx[2 * e + 1] : a.key_edge_idx[2 * e]; };
-            for (int p = lane; p < P; p += 64) {                                  // :323-339
-                const int ip = p / nke, jp = p - ip * nke;
-                const int mpo = a.edge_other[me0 + lxs[ip]];
-                const uint32_t ko = key_other(a.conn_idx[ke0 + jp]);
-                W[p] = mpo == fmp[ko] ? -1.f
-                                      : (a.Dfull ? a.Dfull[(size_t)mpo * a.n + ko] : chain_distance(a.mdesc + (size_t)mpo * 256, a.fdesc + (size_t)ko * 256));
+        for (int ci = 0; ci < nchunk && !overflow; ci++) {
+            const int mp = __builtin_amdgcn_readlane(my_mp, ci);
+            const int w0 = __builtin_amdgcn_readlane(my_w0, ci), cnt = __builtin_amdgcn_readlane(my_w1, ci) - w0;
+            const int cur_id = nx_id;
+            const float cur_d = nx_d;
+            if (ci + 1 < nchunk) {   // the next candidate's window is on its way while this one is processed
+                const int nw0 = __builtin_amdgcn_readlane(my_w0, ci + 1), nw1 = __builtin_amdgcn_readlane(my_w1, ci + 1);
+                if (lane < nw1 - nw0) { nx_id = a.win_idx[nw0 + lane]; nx_d = a.win_dist[nw0 + lane]; }
+            }
+            if (flags[mp] & 3) continue;                                              // :227
+            if (cnt == 0) continue;
+            // :251-270 — best and second best of the window; the first of equal minima wins (window order)
+            float b = 1e6f, b2 = 1e6f;
+            int pos = -1, idx = -1;
+            auto consider = [&](int id, float d, int k) {
+                const int cur = fmp[id];
+                if (cur >= 0 && (flags[cur] & 4)) return;
+                if (d < b) { b2 = b; b = d; pos = k; idx = id; }
+                else if (d < b2) b2 = d;
+            };
+            if (lane < cnt) consider(cur_id, cur_d, lane);
+            for (int k = lane + 64; k < cnt; k += 64) consider(a.win_idx[w0 + k], a.win_dist[w0 + k], k);
+            // distances are non-negative: their bit patterns order like the values
+            const uint32_t gb = wave_min_u32(__float_as_uint(b));
+            const uint32_t gpos = wave_min_u32(__float_as_uint(b) == gb ? (uint32_t)pos : 0xFFFFFFFFu);
+            const bool winner = __float_as_uint(b) == gb && (uint32_t)pos == gpos && pos >= 0;
+            const float best = __uint_as_float(gb);
+            const float best2 = __uint_as_float(wave_min_u32(__float_as_uint(winner ? b2 : b)));
+            if (best > TH_HIGH && best > a.nnratio * best2) continue;                 // :276
+            const unsigned long long wm = __ballot(winner);
+            if (wm == 0) continue;   // every candidate of the window was skipped (the reference would index with -1, :279)
+            const int bestIdx = __builtin_amdgcn_readlane(idx, __builtin_ctzll(wm));
+            const int me0 = __builtin_amdgcn_readlane(my_e0, ci), nme = __builtin_amdgcn_readlane(my_e1, ci) - me0;
+            if (lane == 0) { fmp[bestIdx] = (int16_t)mp; flags[mp] |= 1; queue[0] = (uint16_t)bestIdx; }
+            nmatches++;
+            // lx: the usable map edges of this point, in order (the map side stays the first seed's point, :296)
+            int nlx = 0;
+            if (nme > 0 && nme <= EX_MAXDEG) {
+                const int er = lane < nme ? (int)eother[me0 + lane] : -1;
+                const unsigned long long mrow = __ballot(er >= 0);
+                nlx = __popcll(mrow);
+                if (er >= 0) {
+                    const int p = __popcll(mrow & ((1ull << lane) - 1ull));
+                    lxs[p] = (uint8_t)lane;
+                    rowmp[p] = (int16_t)er;
+                }
             }
             __syncthreads();
-            for (;;) {                                                             // :341-376
-                float bw = 1e6f;
-                int bp = 0x7FFFFFFF;
+            int qh = 0, qt = 1;
+            while (qh < qt) {
+                const int keyID = queue[qh];
+                qh++;
+                const int ke0 = coff[keyID], nke = coff[keyID + 1] - ke0;
+                if (nme == 0 || nke == 0) continue;
+                if (nme > EX_MAXDEG || nke > EX_MAXDEG) { overflow = true; break; }
+                const int P = nlx * nke;
+                if (P > EX_MAXW) { overflow = true; break; }
+                // :323-339 — the weight of every (map edge, key edge) pair, a lane per pair; the lane's first pair stays
+                // in registers (most matrices have at most 64 entries)
+                int ip0 = 0, jp0 = 0;
+                float w0v = 1e6f;
                 for (int p = lane; p < P; p += 64) {
                     const int ip = p / nke, jp = p - ip * nke;
-                    if (rowused[ip] || colused[jp]) continue;
-                    if (W[p] < bw) { bw = W[p]; bp = p; }
+                    const int mpo = rowmp[ip];
+                    const int ko = cother[ke0 + jp];
+                    const float w = mpo == fmp[ko] ? -1.f
+                                                   : (a.Dfull ? a.Dfull[(size_t)mpo * a.n + ko]
+                                                              : chain_distance(a.mdesc + (size_t)mpo * 256, a.fdesc + (size_t)ko * 256));
+                    if (p == lane) { ip0 = ip; jp0 = jp; w0v = w; }
+                    else W[p] = w;
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ow = __shfl_xor(bw, o);
-                    const int op = __shfl_xor(bp, o);
-                    if (ow < bw || (ow == bw && op < bp)) { bw = ow; bp = op; }
-                }
-                if (bw > TH_HIGH || bp == 0x7FFFFFFF) break;
-                const int ip = bp / nke, jp = bp - ip * nke;
-                const int mi = lxs[ip];
-                const int mpo = a.edge_other[me0 + mi];
-                const uint32_t keyEdge = a.conn_idx[ke0 + jp];
-                const uint32_t ko = key_other(keyEdge);
-                const bool take = !(mpo < 0 || a.bad[mpo] || tracked[mpo]);
                 __syncthreads();
-                if (lane == 0) {
-                    rowused[ip] = 1; colused[jp] = 1;
-                    if (take) {
-                        fmp[ko] = mpo;
-                        if (a.frame_me) a.frame_me[keyEdge] = a.edge_id[me0 + mi];
-                        tracked[mpo] = 1;
-                        queue[qt] = (uint16_t)ko;
+                unsigned long long rused = 0, cused = 0;   // (uniform)
+                for (;;) {                                                             // :341-376
+                    // smallest weight among the unused rows and columns, the first in (row, column) order of equal ones;
+                    // weights are -1 or non-negative: key 0 for -1, bit pattern + 1 otherwise
+                    uint32_t bk = 0xFFFFFFFFu;
+                    int bp = 0x7FFFFFFF;
+                    if (lane < P && !((rused >> ip0) & 1) && !((cused >> jp0) & 1) && w0v < 1e6f) {
+                        bk = w0v < 0.f ? 0u : __float_as_uint(w0v) + 1u;
+                        bp = lane;
                     }
+                    for (int p = lane + 64; p < P; p += 64) {
+                        const int ip = p / nke, jp = p - ip * nke;
+                        if (((rused >> ip) & 1) || ((cused >> jp) & 1)) continue;
+                        const float w = W[p];
+                        if (!(w < 1e6f)) continue;
+                        const uint32_t k = w < 0.f ? 0u : __float_as_uint(w) + 1u;
+                        if (k < bk) { bk = k; bp = p; }
+                    }
+                    const uint32_t gk = wave_min_u32(bk);
+                    if (gk == 0xFFFFFFFFu) break;
+                    const float bw = gk == 0u ? -1.f : __uint_as_float(gk - 1u);
+                    if (bw > TH_HIGH) break;
+                    const int gp = (int)wave_min_u32(bk == gk ? (uint32_t)bp : 0xFFFFFFFFu);
+                    const int ip = gp / nke, jp = gp - ip * nke;
+                    const int mpo = rowmp[ip];
+                    const int ko = cother[ke0 + jp];
+                    const bool take = !(flags[mpo] & 3);   // (the other end exists: only usable edges are rows)
+                    rused |= 1ull << ip;
+                    cused |= 1ull << jp;
+                    __syncthreads();
+                    if (take) {
+                        if (lane == 0) {
+                            fmp[ko] = (int16_t)mpo;
+                            flags[mpo] |= 1;
+                            queue[qt] = (uint16_t)ko;
+                            if (a.frame_me) a.frame_me[a.conn_idx[ke0 + jp]] = a.edge_id[me0 + lxs[ip]];
+                        }
+                        qt++;
+                    }
+                    __syncthreads();
                 }
-                if (take) qt++;
-                __syncthreads();
             }
+            nmatches++;   // counted twice per accepted seed (:281, :378)
         }
-        nmatches++;   // counted twice per accepted seed (:281, :378)
     }
     __syncthreads();
-    for (int k = lane; k < a.m; k += 64) a.tracked[k] = tracked[k];
+    for (int k = lane; k < a.m; k += 64) a.tracked[k] = flags[k] & 1;
     for (int k = lane; k < a.n; k += 64) a.frame_mp[k] = fmp[k];
     if (lane == 0) { a.out[0] = nmatches; a.out[1] = overflow ? 1 : 0; }
 }

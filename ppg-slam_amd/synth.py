@@ -99,9 +99,11 @@ def make_frame(height: int, width: int, seed: int, t: int = 0, kind: str = "spar
     return frame_from_scene(make_scene(height, width, seed, kind), height, width, t)
 
 
-def random_map_graph(rng, desc, pos, m, n_medges):
+def random_map_graph(rng, desc, pos, m, n_medges, key_edges=None):
     """A synthetic local map for Matcher::ExtendMapMatches: m map points sampled from a frame's key points (descriptor
-    and projection perturbed) and n_medges random map edges between them, as the flattened arrays of ppg_mapgraph."""
+    and projection perturbed) and n_medges random map edges between them, as the flattened arrays of ppg_mapgraph.
+    With `key_edges` (the frame's [E][2] key edges) every key edge whose two ends were sampled becomes a map edge as
+    well: the map then repeats the frame's own graph, and the seed growing finds consistent neighbours to walk to."""
     n = desc.shape[0]
     src = rng.choice(n, size=m, replace=False)
     mdesc = desc[src] + 0.15 * rng.normal(size=(m, 256)).astype(np.float32) / 16
@@ -111,6 +113,16 @@ def random_map_graph(rng, desc, pos, m, n_medges):
         a, b = rng.choice(m, size=2, replace=False)
         inc[a].append((eid, int(b)))
         inc[b].append((eid, int(a)))
+    if key_edges is not None:
+        where = np.full(n, -1, np.int64)
+        where[src] = np.arange(m)
+        eid = n_medges
+        for s, e in np.asarray(key_edges).reshape(-1, 2):
+            a, b = int(where[s]), int(where[e])
+            if a >= 0 and b >= 0:
+                inc[a].append((eid, b))
+                inc[b].append((eid, a))
+                eid += 1
     ne = sum(len(i) for i in inc)
     other = np.array([o for i in inc for _, o in i], np.int32)
     other[rng.random(ne) < 0.05] = -1

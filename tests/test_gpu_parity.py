@@ -477,9 +477,9 @@ def test_grid_matches_oracle(pkg, orc):
         assert np.array_equal(ctx.features_in_area(pos, x, y, r), orc.features_in_area(cfg, pos, x, y, r))
 
 
-def random_map_graph(rng, desc, pos, m, n_medges):
+def random_map_graph(rng, desc, pos, m, n_medges, key_edges=None):
     import importlib
-    return importlib.import_module("ppg_slam_amd.synth").random_map_graph(rng, desc, pos, m, n_medges)
+    return importlib.import_module("ppg_slam_amd.synth").random_map_graph(rng, desc, pos, m, n_medges, key_edges)
 
 
 def test_extend_map_matches_vs_oracle(pkg, orc, synth):
@@ -995,7 +995,8 @@ def test_waited_results_survive_the_next_submit(pkg, synth):
 def test_extend_map_matches_device_walk(pkg, orc, synth, monkeypatch):
     """The point-pair-graph matcher as one wave on the device against the oracle and against the host walk
     (PPG_EXTEND_HOST=1), on dense frames with many map points and edges; then a graph whose degrees exceed the
-    kernel's limits, which must fall back to the host walk and still agree."""
+    kernel's limits, which must fall back to the host walk and still agree; then wide windows (more than 64 key points
+    each) over a graph whose seeds have weight matrices of more than 64 entries."""
     H, W = 480, 640
     ctx = get_ctx(pkg, W, H, 1024)
     cfg = orc.default_cfg(W, H, 1024)
@@ -1004,7 +1005,7 @@ def test_extend_map_matches_device_walk(pkg, orc, synth, monkeypatch):
     host = pkg.Context(pkg.default_config(W, H, max_num=1024))
     monkeypatch.delenv("PPG_EXTEND_HOST")
     rng = np.random.default_rng(15)
-    for trial, (m, nedges) in enumerate(((800, 1500), (1500, 4000), (300, 9000))):
+    for trial, (m, nedges, th) in enumerate(((800, 1500, 4.0), (1500, 4000, 7.0), (300, 9000, 10.0), (300, 5000, 40.0))):
         g = random_map_graph(rng, r["desc"], r["un"], min(m, r["n"]), nedges)
         mm = g["desc"].shape[0]
         tracked = (rng.random(mm) < 0.05).astype(np.uint8)
@@ -1012,11 +1013,29 @@ def test_extend_map_matches_device_walk(pkg, orc, synth, monkeypatch):
         pre = rng.choice(r["n"], size=40, replace=False)
         fmp[pre] = rng.integers(0, mm, 40)
         fme = np.full(r["n_edges"], -1, np.int32)
-        args = (0.8, 4.0 + 3 * trial, g, r["desc"], r["un"], r["edge_idx"], r["conn_off"], r["conn_idx"], tracked, fmp, fme)
+        args = (0.8, th, g, r["desc"], r["un"], r["edge_idx"], r["conn_off"], r["conn_idx"], tracked, fmp, fme)
         co, to, po, eo = orc.extend_map_matches(cfg, *args)
         cg, tg, pg, eg = ctx.extend_map_matches(*args)
         ch, th_, ph, eh = host.extend_map_matches(*args)
         assert cg == co == ch and np.array_equal(tg, to) and np.array_equal(pg, po) and np.array_equal(eg, eo), trial
         assert np.array_equal(th_, to) and np.array_equal(ph, po) and np.array_equal(eh, eo)
         assert co > 100 and (eo >= 0).sum() > 0
+    # a map that repeats the frame's own graph: most points are reached by the seed growing, through long queues
+    for th in (4.0, 12.0):
+        g = random_map_graph(rng, r["desc"], r["un"], min(900, r["n"]), 300, r["edge_idx"])
+        mm = g["desc"].shape[0]
+        g["in_view"][:] = 1
+        g["bad"][:] = 0
+        tracked = np.zeros(mm, np.uint8)
+        fmp = np.full(r["n"], -1, np.int32)
+        fme = np.full(r["n_edges"], -1, np.int32)
+        args = (0.8, th, g, r["desc"], r["un"], r["edge_idx"], r["conn_off"], r["conn_idx"], tracked, fmp, fme)
+        co, to, po, eo = orc.extend_map_matches(cfg, *args)
+        cg, tg, pg, eg = ctx.extend_map_matches(*args)
+        ch, th_, ph, eh = host.extend_map_matches(*args)
+        assert cg == co == ch and np.array_equal(tg, to) and np.array_equal(pg, po) and np.array_equal(eg, eo), th
+        assert np.array_equal(th_, to) and np.array_equal(ph, po) and np.array_equal(eh, eo)
+        grown = int(to.sum()) - co // 2   # tracked points that were not seeds
+        print(f"graph-shaped map, th {th}: {int(to.sum())} of {mm} map points tracked, {grown} by seed growing, {int((eo >= 0).sum())} edges")
+        assert grown > 100 and (eo >= 0).sum() > 100
     host.close()
