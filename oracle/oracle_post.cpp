@@ -1081,6 +1081,9 @@ void ppgo_bow_transform(const float* desc, int n, int dim, const float* node_des
                 for (int i = 0; i < dim; i++) sqd += (x[i] - y[i]) * (x[i] - y[i]);
                 if (sqd < best_d) { best_d = sqd; final_id = id; }
             }
+            // (a descriptor with NaN components compares nearer to no child and DBoW3 would loop here for ever: the
+            // library and this statement take the first child instead)
+            if (final_id == start) final_id = child_idx[child_off[start]];
             if (current_level == nid_level) nid = final_id;
         } while (child_off[final_id + 1] != child_off[final_id]);
         out_word[f] = word_id[final_id];

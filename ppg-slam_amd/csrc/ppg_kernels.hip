@@ -3368,7 +3368,9 @@ __global__ __launch_bounds__(256) void bow_transform_kernel(BowArgs a) {
             const int op = __shfl_xor(bpos, o);
             if (ob < best || (ob == best && op < bpos)) { best = ob; bpos = op; }
         }
-        // a node whose children are all farther than DBL_MAX cannot occur; bpos is valid when nc > 0
+        // No child compares nearer only for a descriptor with NaN components: DBoW3's loop would then stay at this node
+        // for ever; the first child is taken instead, so that the descent ends and no index is out of range.
+        if (bpos == 0x7FFFFFFF) bpos = 0;
         cur = a.child_idx[c0 + bpos];
         if (level == a.nid_level) nid = cur;
         if (a.child_off[cur + 1] == a.child_off[cur]) break;   // leaf

@@ -94,6 +94,15 @@ def test_bow_transform_vs_oracle(pkg, orc, synth, tmp_path):
                 else:
                     assert len(fv) > 3
             assert len(set(bw[1, :fr[1]["n"]].tolist())) > 50
+        # a descriptor with NaN components is nearer to no child (DBoW3 itself would never return): the descent takes
+        # the first child at every level and ends
+        bad = fr[1]["desc"][:4].copy()
+        bad[1, 7] = np.nan
+        bad[3, :] = np.nan
+        hw, hwt, hnd = pkg.bow_transform(ctx, v, bad, 1)
+        ow, owt, ond = orc.bow_transform(o, bad, 1)
+        assert np.array_equal(hw, ow) and np.array_equal(hwt, owt) and np.array_equal(hnd, ond)
+        assert hw[1] == hw[3] and hw[1] >= 0
     finally:
         ctx.close()
         v.close()
