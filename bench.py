@@ -449,7 +449,7 @@ def main():
                          "frac": round(achieved / peak, 4),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(dom_launches),
                          "flops_per_launch": flops_per_launch, "traffic": None,
-                         "other_3x3_convolutions": {"kernel": "conv_mfma_kernel<3,2,8,false,32|16> (six launches per step)",
+                         "other_3x3_convolutions": {"kernel": "conv_mfma_kernel<3,2,8,false,32|16> (eight launches per step: conv2a-conv4b, the heads' first convolutions in one, EdgeHeatmap block 1)",
                                                     "achieved": round(other_tf, 2) if other_tf else None,
                                                     "ms_per_step": round(o_ms / nb, 4)},
                          "all_convolutions_achieved": round(all_conv_tf, 2)},
