@@ -3405,7 +3405,7 @@ __global__ __launch_bounds__(1024) void match_projected_kernel(ProjMatchArgs a) 
         for (int j = tid; j < a.n2; j += 1024) a.claim[j] = 0xFFFFFFFFu;
         __syncthreads();
         for (int i = tid; i < a.n1; i += 1024)
-            if (a.guess[i] >= 0 && a.row_claims && a.row_claims[i]) atomicMin(&a.claim[a.guess[i]], (uint32_t)i);
+            if (a.guess[i] >= 0 && (a.claim_all || (a.row_claims && a.row_claims[i]))) atomicMin(&a.claim[a.guess[i]], (uint32_t)i);
         __syncthreads();
         int changed = 0;
         for (int i = tid; i < a.n1; i += 1024) {
@@ -3419,8 +3419,9 @@ __global__ __launch_bounds__(1024) void match_projected_kernel(ProjMatchArgs a) 
                 else if (d < second) second = d;
             }
             int m = -1;
-            if (best <= a.th && !(a.ratio > 0.f && best > a.ratio * second)) m = bi;
+            if (a.strict_ratio ? (best <= a.th && best < second * a.ratio) : (best <= a.th && !(a.ratio > 0.f && best > a.ratio * second))) m = bi;
             a.best_dist[i] = best;
+            if (a.second_dist) a.second_dist[i] = second;
             changed |= m != a.guess[i];
             a.best_idx[i] = m;
         }

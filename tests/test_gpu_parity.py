@@ -403,6 +403,30 @@ def test_match_claims_force_fallback(pkg, orc):
     assert cnt_o > 60
 
 
+def test_windowed_claims_contention(pkg, orc):
+    """The windowed claim pass (candidate lists, fixed-point iteration on the device) under heavy contention: clustered
+    descriptors whose rows all lie inside each other's 50-pixel windows, so that most rows find their nearest columns
+    claimed by earlier rows and the iteration needs many rounds; nnratio above and below 1."""
+    rng = np.random.default_rng(19)
+    ctx = get_ctx(pkg, 640, 480)
+    cfg = orc.default_cfg(640, 480)
+    base = unit_rows(rng, 6)
+    A = np.repeat(base, 50, 0) + 0.02 * rng.normal(size=(300, 256)).astype(np.float32)
+    A = (A / np.linalg.norm(A, axis=1, keepdims=True)).astype(np.float32)
+    B = np.repeat(base, 40, 0) + 0.02 * rng.normal(size=(240, 256)).astype(np.float32)
+    B = (B / np.linalg.norm(B, axis=1, keepdims=True)).astype(np.float32)
+    B[7] = B[8]
+    pos = (np.array([300.0, 200.0]) + rng.uniform(-30, 30, (300, 2))).astype(np.float32)
+    pos2 = (np.array([300.0, 200.0]) + rng.uniform(-30, 30, (240, 2))).astype(np.float32)
+    counts = []
+    for ratio in (1.1, 0.95):
+        cnt_o, m_o, prev_o = orc.search_for_initialization(cfg, ratio, A, B, pos2, pos, 50)
+        cnt_g, m_g, prev_g = ctx.search_for_initialization(ratio, A, B, pos2, pos, 50)
+        assert cnt_g == cnt_o and np.array_equal(m_g, m_o) and np.array_equal(prev_g, prev_o), ratio
+        counts.append(cnt_o)
+    assert counts[0] > 100 and counts[1] > 5
+
+
 def test_match_frames_resident(pkg, orc, synth):
     H, W = 480, 640
     ctx = get_ctx(pkg, W, H, 1024, batch=2)
