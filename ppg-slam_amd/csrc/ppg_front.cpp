@@ -1576,7 +1576,6 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     if (!rc && csr) rc = grow(c, c->mOff, (size_t)nA + 1);
     if (!rc && csr) rc = grow(c, c->mIdx, std::max<size_t>(nd, 1));
     if (!rc && skipB) rc = grow(c, c->mSkip, std::max(nB, 1));
-    if (!rc && csr && mode == PPG_MATCH_INIT) rc = grow(c, c->mClaim, std::max(nB, 1));
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->mA.p, A, sizeof(float) * nA * dim, hipMemcpyHostToDevice, s));
     if (nB) HIPCHK(c, hipMemcpyAsync(c->mB.p, B, sizeof(float) * nB * dim, hipMemcpyHostToDevice, s));
@@ -1609,16 +1608,6 @@ int ppg_match_nn(ppg_ctx* c, const float* A, int nA, const float* B, int nB, int
     }
     if (fused) { /* enqueued above */ }
     else if (mode == PPG_MATCH_PLAIN) HIPCHK(c, ppg::launch_match_plain(m, s));
-    else if (csr) {
-        // windowed claim matching (SearchForInitialization with its 50-pixel windows, Matcher.cpp:591-644): the
-        // sequential pass over the candidate lists as a fixed point, all rows at once
-        ppg::ProjMatchArgs pm;
-        pm.D = c->mD.p; pm.cand_off = c->mOff.p; pm.cand_idx = c->mIdx.p; pm.n1 = nA; pm.n2 = nB;
-        pm.blocked_in = skipB ? c->mSkip.p : nullptr; pm.row_claims = nullptr; pm.claim_all = 1; pm.strict_ratio = 1;
-        pm.th = th; pm.ratio = ratio; pm.claim = c->mClaim.p; pm.guess = c->mTopI.p; pm.best_idx = c->mMatch.p;
-        pm.best_dist = c->mBest.p; pm.second_dist = c->mSecond.p; pm.blocked_out = nullptr; pm.n_matches = c->mCount;
-        HIPCHK(c, ppg::launch_match_projected(pm, s));
-    }
     else HIPCHK(c, ppg::launch_match_init(m, s));
     HIPCHK(c, hipMemcpyAsync(match12, c->mMatch.p, sizeof(int32_t) * nA, hipMemcpyDeviceToHost, s));
     if (best) HIPCHK(c, hipMemcpyAsync(best, c->mBest.p, sizeof(float) * nA, hipMemcpyDeviceToHost, s));

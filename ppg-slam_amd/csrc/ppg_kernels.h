@@ -240,15 +240,11 @@ struct ProjMatchArgs {
     int n1, n2;
     const uint8_t* blocked_in; // [n2] or nullptr
     const uint8_t* row_claims; // [n1] or nullptr
-    int claim_all = 0;         // every accepted row claims its slot (row_claims is not read)
-    int strict_ratio = 0;      // accept iff best <= th and best < ratio * second (SearchForInitialization, Matcher.cpp:630)
-                               // instead of best <= th and not (ratio > 0 and best > ratio * second)
     float th, ratio;
     uint32_t* claim;           // [n2] work
     int32_t* guess;            // [n1] work
     int32_t* best_idx;         // [n1]
     float* best_dist;          // [n1]
-    float* second_dist = nullptr;  // [n1] or nullptr: the second smallest distance among the candidates the row could take
     uint8_t* blocked_out;      // [n2] or nullptr
     int* n_matches;
 };

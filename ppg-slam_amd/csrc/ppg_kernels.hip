@@ -2731,11 +2731,108 @@ __global__ __launch_bounds__(64) void match_init_resolve_kernel(MatchArgs a) {
     if (lane == 0) *a.n_matches = nmatches;
 }
 
+// INIT step 2 for problems of at most MJ_MAX rows on either side: the same pass as a fixed point, all rows at once.
+// Row i's match depends only on the claims of the rows before it, so a guess of every row's match that reproduces
+// itself when each row recomputes its own from the claims the guesses of the earlier rows imply IS the sequential result
+// (rows 0..t-1 are final after round t; a handful of rounds in practice, at most nA + 1).  A thread per row works
+// from the row's eight-nearest list; the rows whose list cannot supply two free candidates (while the row has more than
+// eight) are queued and scanned whole, a wave per row, reading the row's distances side by side.  Claims (the
+// smallest row whose guess is the column), guesses and the queue live in LDS.
+constexpr int MJ_MAX = 8192;
+
+__global__ __launch_bounds__(1024) void match_init_jacobi_kernel(MatchArgs a) {
+    __shared__ uint32_t claim[MJ_MAX];
+    __shared__ int32_t guess[MJ_MAX];
+    __shared__ uint16_t fb_rows[MJ_MAX];
+    __shared__ int nfb, tot;
+    apply_batch(a, blockIdx.x);
+    const int nA = a.nA_dev ? min(a.nA, *a.nA_dev) : a.nA, nB = a.nB_dev ? min(a.nB, *a.nB_dev) : a.nB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < nA; i += 1024) guess[i] = -1;
+    if (tid == 0) tot = 0;
+    __syncthreads();
+    for (int round = 0; round <= nA; round++) {
+        for (int j = tid; j < nB; j += 1024) claim[j] = 0xFFFFFFFFu;
+        if (tid == 0) nfb = 0;
+        __syncthreads();
+        for (int i = tid; i < nA; i += 1024) {
+            const int g = guess[i];
+            if (g >= 0) atomicMin(&claim[g], (uint32_t)i);
+        }
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < nA; i += 1024) {
+            const f32x4 d0 = *(const f32x4*)(a.topk_dist + (size_t)i * TOPK), d1 = *(const f32x4*)(a.topk_dist + (size_t)i * TOPK + 4);
+            const int4 i0 = *(const int4*)(a.topk_idx + (size_t)i * TOPK), i1 = *(const int4*)(a.topk_idx + (size_t)i * TOPK + 4);
+            const float d[TOPK] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            const int id[TOPK] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+            float best = 1e6f, second = 1e6f;
+            int bidx = -1, nfree = 0, nlisted = 0;
+#pragma unroll
+            for (int t = 0; t < TOPK; t++) {
+                if (id[t] < 0) continue;
+                nlisted++;
+                if (claim[id[t]] < (uint32_t)i) continue;   // taken by an earlier row
+                if (nfree == 0) { best = d[t]; bidx = id[t]; }
+                else if (nfree == 1) second = d[t];
+                nfree++;
+            }
+            if (nfree < 2 && nlisted == TOPK) {   // the list ran dry and the row has more candidates
+                fb_rows[atomicAdd(&nfb, 1)] = (uint16_t)i;
+                continue;
+            }
+            const int m = (bidx >= 0 && best <= a.th && best < second * a.ratio) ? bidx : -1;
+            changed |= m != guess[i];
+            guess[i] = m;   // (read again only by this thread, when the claims of the next round are built)
+            a.best[i] = best;
+            a.second[i] = second;
+        }
+        __syncthreads();
+        const int nq = nfb;
+        for (int q = wave; q < nq; q += 16) {
+            const int i = fb_rows[q];
+            const float* drow; const int32_t* irow; int cnt;
+            row_candidates(a, i, nB, &drow, &irow, &cnt);
+            Best2 v = {1e6f, 1e6f, -1, -1};
+            for (int k = lane; k < cnt; k += 64) {
+                const int idx = irow ? irow[k] : k;
+                if (a.skipB && a.skipB[idx]) continue;
+                if (claim[idx] < (uint32_t)i) continue;
+                const float dd = drow[k];
+                if (dd < v.b) { v.b2 = v.b; v.b = dd; v.pos = k; v.idx = idx; }
+                else if (dd < v.b2) v.b2 = dd;
+            }
+            v = best2_wave(v);
+            if (lane == 0) {
+                const int m = (v.idx >= 0 && v.b <= a.th && v.b < v.b2 * a.ratio) ? v.idx : -1;
+                changed |= m != guess[i];
+                guess[i] = m;
+                a.best[i] = v.b;
+                a.second[i] = v.b2;
+            }
+        }
+        if (!__syncthreads_count(changed)) break;
+    }
+    int cnt = 0;
+    for (int i = tid; i < nA; i += 1024) {
+        const int m = guess[i];
+        a.match12[i] = m;
+        cnt += m >= 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0 && cnt) atomicAdd(&tot, cnt);
+    __syncthreads();
+    if (tid == 0) *a.n_matches = tot;
+}
+
 hipError_t launch_match_init(const MatchArgs& a, hipStream_t s) {
     const int rows = a.nA;
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(match_topk_kernel, dim3((rows + 3) / 4, a.batch), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(match_init_resolve_kernel, dim3(a.batch), dim3(64), 0, s, a);
+    // the one-wave replay only where the fixed point's tables would not fit LDS
+    if (a.nA <= MJ_MAX && a.nB <= MJ_MAX) hipLaunchKernelGGL(match_init_jacobi_kernel, dim3(a.batch), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(match_init_resolve_kernel, dim3(a.batch), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
@@ -3405,7 +3502,7 @@ __global__ __launch_bounds__(1024) void match_projected_kernel(ProjMatchArgs a) 
         for (int j = tid; j < a.n2; j += 1024) a.claim[j] = 0xFFFFFFFFu;
         __syncthreads();
         for (int i = tid; i < a.n1; i += 1024)
-            if (a.guess[i] >= 0 && (a.claim_all || (a.row_claims && a.row_claims[i]))) atomicMin(&a.claim[a.guess[i]], (uint32_t)i);
+            if (a.guess[i] >= 0 && a.row_claims && a.row_claims[i]) atomicMin(&a.claim[a.guess[i]], (uint32_t)i);
         __syncthreads();
         int changed = 0;
         for (int i = tid; i < a.n1; i += 1024) {
@@ -3419,9 +3516,8 @@ __global__ __launch_bounds__(1024) void match_projected_kernel(ProjMatchArgs a) 
                 else if (d < second) second = d;
             }
             int m = -1;
-            if (a.strict_ratio ? (best <= a.th && best < second * a.ratio) : (best <= a.th && !(a.ratio > 0.f && best > a.ratio * second))) m = bi;
+            if (best <= a.th && !(a.ratio > 0.f && best > a.ratio * second)) m = bi;
             a.best_dist[i] = best;
-            if (a.second_dist) a.second_dist[i] = second;
             changed |= m != a.guess[i];
             a.best_idx[i] = m;
         }
