@@ -189,6 +189,14 @@ def matcher_timings(pkg, synth, H, W, args, device_id):
     off, idx = np.array(off, np.int32), np.array(idx if idx else [0], np.int32)
     out["windowed_nearest_neighbour_r15"] = {"gpu": best(lambda: ctx.match_nn(f0["desc"], f1["desc"], off, idx, None, 0.8, 0.0, pkg.MATCH_PLAIN)),
                                              "candidates": int(off[-1])}
+    # Matcher::SearchByProjection(Frame&, const Frame&, th) (Matcher.cpp:31-87), the matcher of every tracked frame: the
+    # last frame's points projected into the current one search 15-pixel windows, accepted rows claim their slot
+    uv = f0["un"] + np.array([3.0, 1.0], np.float32)
+    out["SearchByProjection_r15"] = {
+        "gpu": best(lambda: ctx.match_projected(f1["un"], f1["desc"], f0["desc"], uv, 15.0, 0.8, 0.0, None,
+                                                np.ones(f0["n"], np.uint8), np.zeros(f1["n"], np.uint8))),
+        "matches": int(ctx.match_projected(f1["un"], f1["desc"], f0["desc"], uv, 15.0, 0.8, 0.0, None,
+                                           np.ones(f0["n"], np.uint8), np.zeros(f1["n"], np.uint8))[0])}
     segs = np.arange(0, f1["n"] + 1, 8, dtype=np.int32)
     out["ComputeDistinctiveDescriptors_8obs"] = {
         "gpu": best(lambda: ctx.distinctive_descriptors(f1["desc"][:segs[-1]], segs)),

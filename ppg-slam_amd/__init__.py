@@ -368,6 +368,42 @@ class Context:
         self.L.ppg_grid_free(C.c_void_p(g))
         return out[:cnt].copy()
 
+    def match_projected(self, pos2, desc2, desc1, uv, radius, th, ratio=0.0, row_ok=None, row_claims=None,
+                        slot_blocked=None, e2_max=-1.0):
+        """ppg_match_projected: the windowed search shared by Matcher::SearchByProjection / Fuse.  Row i (descriptor
+        desc1[i], projected to uv[i], window radius[i]) searches the key points at pos2 (undistorted) with descriptors
+        desc2.  Returns (n_matches, best_idx, best_dist, slot_blocked after the call or None)."""
+        pos2 = np.ascontiguousarray(pos2, np.float32)
+        desc2 = np.ascontiguousarray(desc2, np.float32)
+        desc1 = np.ascontiguousarray(desc1, np.float32)
+        uv = np.ascontiguousarray(uv, np.float32)
+        n1, n2 = desc1.shape[0], desc2.shape[0]
+        radius = np.ascontiguousarray(np.broadcast_to(np.asarray(radius, np.float32), (n1,)))
+        keep = [pos2, desc2, desc1, uv, radius]
+        a = ProjArgs()
+        g = self.L.ppg_grid_build(C.byref(self.cfg), _p(pos2), n2)
+        a.grid = g
+        a.desc2, a.n2, a.desc1, a.n1 = desc2.ctypes.data, n2, desc1.ctypes.data, n1
+        a.uv, a.radius = uv.ctypes.data, radius.ctypes.data
+        for name, arr in (("row_ok", row_ok), ("row_claims", row_claims)):
+            if arr is not None:
+                arr = np.ascontiguousarray(arr, np.uint8)
+                keep.append(arr)
+                setattr(a, name, arr.ctypes.data)
+        blocked = None
+        if slot_blocked is not None:
+            blocked = np.array(slot_blocked, np.uint8, copy=True)
+            a.slot_blocked = blocked.ctypes.data
+        a.th, a.ratio, a.e2_max = th, ratio, e2_max
+        best_idx = np.full(max(n1, 1), -1, np.int32)
+        best_dist = np.zeros(max(n1, 1), np.float32)
+        cnt = C.c_int(0)
+        try:
+            self._chk(self.L.ppg_match_projected(C.c_void_p(self.h), C.byref(a), _p(best_idx), _p(best_dist), C.byref(cnt)))
+        finally:
+            self.L.ppg_grid_free(C.c_void_p(g))
+        return cnt.value, best_idx[:n1], best_dist[:n1], blocked
+
     def extend_map_matches(self, nnratio, th, g, desc, pos_un, edge_idx, conn_off, conn_idx, tracked, frame_mp, frame_me):
         keep = {k: np.ascontiguousarray(v) for k, v in g.items()}
         mg = MapGraph()
@@ -387,6 +423,13 @@ class Context:
                                                 _p(pos_un), desc.shape[0], _p(edge_idx), edge_idx.shape[0], _p(conn_off),
                                                 _p(conn_idx), _p(tracked), _p(frame_mp), _p(frame_me), C.byref(cnt)))
         return cnt.value, tracked, frame_mp, frame_me
+
+
+class ProjArgs(C.Structure):
+    """ppg_proj_args (include/ppgfront.h)."""
+    _fields_ = [("grid", C.c_void_p), ("desc2", C.c_void_p), ("n2", C.c_int), ("desc1", C.c_void_p), ("n1", C.c_int),
+                ("uv", C.c_void_p), ("radius", C.c_void_p), ("row_ok", C.c_void_p), ("row_claims", C.c_void_p),
+                ("slot_blocked", C.c_void_p), ("th", C.c_float), ("ratio", C.c_float), ("e2_max", C.c_float)]
 
 
 class Vocabulary:
