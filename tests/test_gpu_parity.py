@@ -366,7 +366,7 @@ def test_match_plain_vs_oracle(pkg, orc):
     assert np.array_equal(m2, D.argmin(1)) and np.array_equal(best2, D.min(1))
 
 
-@pytest.mark.parametrize("n,window", [(60, 0), (500, 0), (1024, 0), (300, 50), (1024, 50), (2048, 0), (3000, 80)])
+@pytest.mark.parametrize("n,window", [(60, 0), (500, 0), (1024, 0), (300, 50), (1024, 50), (2048, 0), (3000, 80), (8200, 30)])
 def test_search_for_initialization_vs_oracle(n, window, pkg, orc):
     rng = np.random.default_rng(3 + n)
     ctx = get_ctx(pkg, 640, 480)
