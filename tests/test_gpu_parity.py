@@ -456,6 +456,26 @@ def test_match_prev_batch_resident(pkg, orc, synth):
         ctx.match_prev_batch(4, 0.9)
 
 
+def test_match_prev_batch_resident_beyond_1024_keypoints(pkg, orc, synth):
+    """JUNCTION_MAX_NUM = 2048: the resident frame-to-frame match leaves the matrix-free path (at most 1024 rows) for the
+    batched distance matrix, the eight-nearest lists and the fixed-point claim pass; two streams of 768 x 1024 frames."""
+    H, W = 768, 1024
+    ctx = pkg.Context(pkg.default_config(W, H, max_batch=2, max_num=2048))
+    try:
+        cfg = orc.default_cfg(W, H, 2048)
+        scenes = [(11, "dense"), (12, "dense")]
+        r0 = ctx.extract_batch([synth.make_frame(H, W, s, 0, k) for s, k in scenes])
+        r1 = ctx.extract_batch([synth.make_frame(H, W, s, 1, k) for s, k in scenes])
+        assert max(r["n"] for r in r0) > 1024, [r["n"] for r in r0]
+        cnts, m12 = ctx.match_prev_batch(2, 0.9)
+        for b in range(2):
+            co, mo, _ = orc.search_for_initialization(cfg, 0.9, r0[b]["desc"], r1[b]["desc"], r1[b]["un"], r0[b]["un"], 0)
+            assert cnts[b] == co and np.array_equal(m12[b, :r0[b]["n"]], mo) and np.all(m12[b, r0[b]["n"]:] == -1)
+        assert cnts.sum() > 800
+    finally:
+        ctx.close()
+
+
 def test_pipelined_submit_wait_equals_blocking(pkg, synth):
     """Four batches in flight: results (frames and matches) must equal the blocking calls bit for bit."""
     H, W = 96, 128

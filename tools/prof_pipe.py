@@ -12,6 +12,9 @@ pkg = load_pkg()
 synth = importlib.import_module("ppg_slam_amd.synth")
 H, W, B = 480, 640, int(sys.argv[1]) if len(sys.argv) > 1 else 1
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+idle = None
+if os.environ.get("PROF_IDLE_CTX"):   # a second, idle context of 32 streams beside the measured one (what bench.py's sweep runs beside)
+    idle = pkg.Context(pkg.default_config(W, H, max_batch=32, max_num=1024))
 ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=1024))
 scenes = [synth.make_scene(H, W, 1000 * s + 11, "dense") for s in range(B)]
 frames = [[synth.frame_from_scene(scenes[s], H, W, t) for s in range(B)] for t in range(8)]
@@ -26,3 +29,5 @@ for t in range(steps + depth):
 dt = time.perf_counter() - t0
 print("B=%d: %.1f frames/s, %.3f ms per step" % (B, B * steps / dt, 1e3 * dt / steps))
 ctx.close()
+if idle is not None:
+    idle.close()
