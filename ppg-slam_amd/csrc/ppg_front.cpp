@@ -229,6 +229,7 @@ struct ppg_ctx {
     // times as many tiles (each work-group then walks the tiles with that stride; 0 = one work-group per tile).
     // PPG_CONV_PERSIST="f,o" overrides both.
     int persist_fused = 0, persist_other = 0;
+    int xcd_group = 4, xcd_band = 1;   // XCD-aware launch order of the convolutions (ppg::ConvArgs::xcd_group); PPG_XCD_MAP=0 switches it off
     bool persist_forced = false;  // set by PPG_CONV_PERSIST: the numbers apply to every launch, whatever its size
     bool no_quarter = false;    // PPG_NO_QUARTER_TILES=1: big convolution tiles whatever the batch size (read at ppg_create)
     bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
@@ -665,6 +666,7 @@ void conv_tiling(const ppg_ctx* c, ppg::ConvArgs& a, const DevConv& dc, int mode
     a.persist = (fused ? c->persist_fused : c->persist_other);
     if (!c->persist_forced && (long)a.tiles_x * a.tiles_y * a.B < 20L * a.persist) a.persist = 0;
     a.tile_counter = c->lane[c->lane_cur].tile_ctr;
+    a.xcd_group = c->xcd_group; a.xcd_band = c->xcd_band;
     if (c->no_quarter || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
     if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;
     a.quarter = 1;
@@ -872,6 +874,8 @@ static int create_impl(ppg_ctx* c) {
         const char* mm = getenv("PPG_MATCH_MATRIX");
         c->match_matrix = mm && atoi(mm) != 0;
         if (const char* pe = getenv("PPG_CONV_PERSIST")) c->persist_forced = sscanf(pe, "%d,%d", &c->persist_fused, &c->persist_other) == 2;
+        if (const char* xm = getenv("PPG_XCD_MAP")) c->xcd_group = std::max(0, atoi(xm));
+        if (const char* xb = getenv("PPG_XCD_BAND")) c->xcd_band = atoi(xb) != 0;
         const char* nq = getenv("PPG_NO_QUARTER_TILES");
         c->no_quarter = nq && atoi(nq) != 0;
         const char* eh = getenv("PPG_EXTEND_HOST");

@@ -35,6 +35,16 @@ struct ConvArgs {
     int persist = 0;             // fp32 kernels: > 0 caps the work-groups per cout block (each then takes several tiles)
     int* tile_counter = nullptr; // 2 * nblk zeroed ints the tiles are handed out through when persist applies (the kernel zeroes them again)
     int mw = 32;         // tile shape: 32 -> 8 x 32 pixels, 16 -> 16 x 16 pixels (3x3, 64-cout blocks only)
+    // XCD-aware launch order.  Work-groups of a launch go round the eight XCDs (work-group L runs on XCD L % 8), each
+    // with its own L2.  xcd_group = G > 0 (the launch function lowers it to a divisor of the cout blocks) turns a launch
+    // of one work-group per tile into a one-dimensional one of 8 * xcd_tiles8 * (cout blocks) work-groups in which XCD x
+    // serves the band of tiles x * xcd_tiles8 ... in order (xcd_band; otherwise the tiles t with t % 8 == x) and the G
+    // cout blocks of a group that share a tile are dispatched back to back onto that XCD: neighbouring tiles find their
+    // common halo, and the blocks of a group their whole input tile, in the XCD's L2 instead of fetching it again.
+    // Work-group L: x = L % 8, k = L / 8, block in group k % G, tile slot (k / G) % xcd_tiles8, group k / G / xcd_tiles8.
+    int xcd_group = 0;
+    int xcd_band = 1;
+    int xcd_tiles8 = 0;  // set by the launch function: ceil(tiles / 8)
     int quarter = 0;     // 1: quarter-size work-groups (fp32 3x3, 64-cout blocks): 4 x 32 (mw 32) or 8 x 16 (mw 16) pixels x 32 couts
     int ngroups = 1;
     ConvGroup g[3];

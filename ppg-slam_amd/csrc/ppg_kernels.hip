@@ -204,8 +204,14 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     // tile_counter[2 * cout block + 1]) puts both counters back to zero for the next launch.
     __shared__ int next_tile;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    int* tctr = a.tile_counter ? a.tile_counter + 2 * blockIdx.y : nullptr;
-    int bx = blockIdx.x;
+    int bx = blockIdx.x, nby_ = blockIdx.y;
+    if (a.xcd_group > 0) {   // (never together with the tile counter)
+        const int k = blockIdx.x >> 3, r = k / a.xcd_group;
+        nby_ = (r / a.xcd_tiles8) * a.xcd_group + k % a.xcd_group;
+        bx = a.xcd_band ? (blockIdx.x & 7) * a.xcd_tiles8 + r % a.xcd_tiles8 : (r % a.xcd_tiles8) * 8 + (blockIdx.x & 7);
+        if (bx >= ntiles) return;
+    }
+    int* tctr = a.tile_counter ? a.tile_counter + 2 * nby_ : nullptr;
     if (tctr) {
         if (threadIdx.x == 0) next_tile = atomicAdd(tctr, 1);
         __syncthreads();
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     tm0 = wall_clock64();
 #endif
     const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, b = bx / (a.tiles_x * a.tiles_y);
-    const int nb = blockIdx.y;
+    const int nb = nby_;
     const int x0 = tx * TW, y0 = ty * TH;
     const int nchunks = a.Cin / KC;
     // pixel (row, column) inside the tile of A-operand lane li / accumulator row index i of M tile m
@@ -477,9 +483,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
     const long long tm0 = wall_clock64();
 #endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int bx = blockIdx.x;
+    int bx = blockIdx.x, nb = blockIdx.y;
+    if (a.xcd_group > 0) {
+        const int k = blockIdx.x >> 3, r = k / a.xcd_group;
+        nb = (r / a.xcd_tiles8) * a.xcd_group + k % a.xcd_group;
+        bx = a.xcd_band ? (blockIdx.x & 7) * a.xcd_tiles8 + r % a.xcd_tiles8 : (r % a.xcd_tiles8) * 8 + (blockIdx.x & 7);
+        if (bx >= a.tiles_x * a.tiles_y * a.B) return;
+    }
     const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, b = bx / (a.tiles_x * a.tiles_y);
-    const int nb = blockIdx.y;
     const int x0 = tx * TW, y0 = ty * TH;
     const int nchunks = a.Cin / KC;
     auto prow = [&](int m, int i) { return MW == 32 ? 2 * wave + m : 4 * wave + 2 * m + (i >> 4); };
@@ -683,11 +694,23 @@ hipError_t launch_conv(const ConvArgs& args, int ks, int nt, hipStream_t s) {
     // fp32 kernels: at most `persist` work-groups per cout block, each walking the tiles with that stride
     if (a.persist > 0 && a.prec == 0 && a.tile_counter && (int)grid.x > a.persist) grid.x = a.persist;
     if ((int)grid.x == a.tiles_x * a.tiles_y * a.B) a.tile_counter = nullptr;  // one work-group per tile: no counter
+    // XCD-aware order of the work-groups (see ConvArgs::xcd_group) for launches of one work-group per tile
+    const int nby = a.quarter ? 2 * a.nblk : a.nblk;
+    const int want = a.xcd_group;
+    a.xcd_group = 0;
+    if (want > 0 && !a.tile_counter) {
+        int G = std::min(nby, want);
+        while (nby % G) G--;   // the largest group size up to the asked one that divides the cout blocks
+        a.xcd_group = G;
+        a.xcd_tiles8 = (int)(((long)a.tiles_x * a.tiles_y * a.B + 7) / 8);
+        grid.x = (unsigned)((long)a.xcd_tiles8 * 8 * nby);
+        grid.y = 1;
+    }
     if (a.quarter) {
         // quarter-size work-groups: fp32 3x3 layers with 64-cout blocks only; tiles_x / tiles_y count 4 x 32 or 8 x 16 tiles
         if (ks != 3 || nt != 2 || a.img || a.prec != 0 || a.ngroups < 1 || a.ngroups > 3) return hipErrorInvalidValue;
         if ((long)a.H * a.W * a.Cin * 4 > 0x7fffffffL) return hipErrorInvalidValue;
-        grid.y = 2 * a.nblk;
+        grid.y = a.xcd_group ? 1 : 2 * a.nblk;
         if (a.mw == 16) hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8, false, 16, 1, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((conv_mfma_kernel<3, 1, 8, false, 32, 1, true>), grid, block, 0, s, a);
         return hipGetLastError();

@@ -191,6 +191,35 @@ def test_quarter_tiles_equal_big_tiles(pkg, synth, monkeypatch):
             big.close()
 
 
+def test_xcd_order_equals_plain_order(pkg, synth, monkeypatch):
+    """Convolution launches of one work-group per tile are dispatched in an XCD-aware order (bands of tiles per XCD, the
+    cout blocks of a group sharing a tile back to back); PPG_XCD_MAP=0 keeps the plain (tile, cout block) grid, other
+    values other group sizes, PPG_XCD_BAND=0 the interleaved tile assignment.  The order must not change a bit of any
+    output, in any arithmetic mode, on sizes whose tile counts are not multiples of eight, with and without quarter-size
+    work-groups."""
+    for (H, W, n, prec) in ((480, 640, 1, 0), (96, 128, 3, 0), (72, 104, 2, 3), (120, 136, 5, 1), (480, 640, 6, 0)):
+        imgs = [synth.make_frame(H, W, 910 + k, 0, "dense" if k % 2 else "sparse") for k in range(n)]
+        ctxs = []
+        for env in ({"PPG_XCD_MAP": "0"}, {}, {"PPG_XCD_MAP": "64"}, {"PPG_XCD_MAP": "3", "PPG_XCD_BAND": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ctxs.append(pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500, precision=prec)))
+            for k in env:
+                monkeypatch.delenv(k)
+        try:
+            res = [c.extract_batch(imgs) for c in ctxs]
+            for c, r in zip(ctxs[1:], res[1:]):
+                for which in (pkg.T_FEAT, pkg.T_JUNC, pkg.T_HEAT_RAW, pkg.T_DESCMAP, pkg.T_SCORE, pkg.T_HEAT):
+                    for f in range(n):
+                        assert np.array_equal(ctxs[0].read_tensor(which, f), c.read_tensor(which, f)), (H, W, n, prec, which, f)
+                for a, b in zip(res[0], r):
+                    assert np.array_equal(a["xy"], b["xy"]) and np.array_equal(a["desc"], b["desc"])
+                    assert np.array_equal(a["edge_idx"], b["edge_idx"])
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 def test_tile_walk_equals_one_group_per_tile(pkg, synth, monkeypatch):
     """Large launches of the fused first convolution run a fixed number of work-groups that take their tiles from a counter
     (which the kernel leaves at zero for the next launch: every context below extracts twice);
