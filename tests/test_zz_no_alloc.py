@@ -23,24 +23,74 @@ def _pair(rng, nA, nB):
     return A, B
 
 
-def _run_noalloc(ctx, torch, A, B, mode, th, ratio, stream=None):
+class _Hip:
+    """The few HIP runtime calls the test needs for the caller's side (device buffers, a stream), through the runtime
+    libppgfront itself is linked against: one HIP runtime in the process, no second one brought in by another package."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so.7")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.rt.hipStreamDestroy.argtypes = [C.c_void_p]
+        self.live = []
+
+    def _ok(self, rc, what):
+        assert rc == 0, f"{what} failed with HIP error {rc}"
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.C.c_void_p()
+        self._ok(self.rt.hipMalloc(self.C.byref(p), max(arr.nbytes, 16)), "hipMalloc")
+        self.live.append(p)
+        if arr.nbytes:
+            self._ok(self.rt.hipMemcpy(p, arr.ctypes.data_as(self.C.c_void_p), arr.nbytes, 1), "hipMemcpy H2D")
+        return p
+
+    def to_host(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            self._ok(self.rt.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), p, out.nbytes, 2), "hipMemcpy D2H")
+        return out
+
+    def stream(self):
+        s = self.C.c_void_p()
+        self._ok(self.rt.hipStreamCreate(self.C.byref(s)), "hipStreamCreate")
+        return s
+
+    def sync(self):
+        self._ok(self.rt.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+    def free_all(self):
+        for p in self.live:
+            self.rt.hipFree(p)
+        self.live = []
+
+
+def _run_noalloc(ctx, hip, A, B, mode, th, ratio, stream=None):
     nA, nB = A.shape[0], B.shape[0]
-    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
-    dm = torch.full((max(nA, 1),), -7, dtype=torch.int32, device="cuda")
-    db = torch.full((max(nA, 1),), -7.0, dtype=torch.float32, device="cuda")
-    ds = torch.full((max(nA, 1),), -7.0, dtype=torch.float32, device="cuda")
-    dc = torch.full((1,), -7, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    rc = ctx.match_nn_noalloc(dA.data_ptr(), nA, dB.data_ptr(), nB, dm.data_ptr(), db.data_ptr(), ds.data_ptr(), dc.data_ptr(),
+    dA, dB = hip.to_device(A), hip.to_device(B)
+    dm = hip.to_device(np.full(max(nA, 1), -7, np.int32))
+    db = hip.to_device(np.full(max(nA, 1), -7.0, np.float32))
+    ds = hip.to_device(np.full(max(nA, 1), -7.0, np.float32))
+    dc = hip.to_device(np.full(1, -7, np.int32))
+    hip.sync()
+    rc = ctx.match_nn_noalloc(dA.value, nA, dB.value, nB, dm.value, db.value, ds.value, dc.value,
                               th=th, ratio=ratio, mode=mode, stream=stream)
     assert rc == 0, ctx.last_error()
-    torch.cuda.synchronize()
-    return dm.cpu().numpy()[:nA], db.cpu().numpy()[:nA], ds.cpu().numpy()[:nA], int(dc.cpu()[0])
+    hip.sync()
+    out = (hip.to_host(dm, max(nA, 1), np.int32)[:nA], hip.to_host(db, max(nA, 1), np.float32)[:nA],
+           hip.to_host(ds, max(nA, 1), np.float32)[:nA], int(hip.to_host(dc, 1, np.int32)[0]))
+    hip.free_all()
+    return out
 
 
 def test_noalloc_match_equals_allocating_entry_point(pkg):
-    import torch
     ctx = pkg.Context(pkg.default_config(128, 96))
+    hip = _Hip()
     try:
         rng = np.random.default_rng(77)
         # two calls in a row per mode, the second smaller; then ragged and degenerate shapes
@@ -49,7 +99,7 @@ def test_noalloc_match_equals_allocating_entry_point(pkg):
                 A, B = _pair(rng, nA, max(nB, 1))
                 B = B[:nB]
                 m_ref, b_ref, s_ref, c_ref = ctx.match_nn(A, B, th=0.7, ratio=0.9, mode=mode)
-                m, b, s, cnt = _run_noalloc(ctx, torch, A, B, mode, 0.7, 0.9)
+                m, b, s, cnt = _run_noalloc(ctx, hip, A, B, mode, 0.7, 0.9)
                 assert np.array_equal(m, m_ref), (mode, nA, nB)
                 assert np.array_equal(b, b_ref) and np.array_equal(s, s_ref), (mode, nA, nB)
                 if mode == pkg.MATCH_INIT:
@@ -58,15 +108,16 @@ def test_noalloc_match_equals_allocating_entry_point(pkg):
                         assert cnt > min(nA, nB) // 8
         # on a caller's stream the call only enqueues
         A, B = _pair(rng, 400, 380)
-        st = torch.cuda.Stream()
+        st = hip.stream()
         m_ref, b_ref, s_ref, c_ref = ctx.match_nn(A, B, th=0.7, ratio=0.9, mode=pkg.MATCH_INIT)
-        m, b, s, cnt = _run_noalloc(ctx, torch, A, B, pkg.MATCH_INIT, 0.7, 0.9, stream=st.cuda_stream)
+        m, b, s, cnt = _run_noalloc(ctx, hip, A, B, pkg.MATCH_INIT, 0.7, 0.9, stream=st.value)
+        hip.rt.hipStreamDestroy(st)
         assert np.array_equal(m, m_ref) and np.array_equal(b, b_ref) and np.array_equal(s, s_ref) and cnt == c_ref
         # beyond the fixed work memory: a clear error, nothing launched
-        big = torch.zeros((1025, 256), dtype=torch.float32, device="cuda")
-        out = torch.zeros((1025,), dtype=torch.int32, device="cuda")
-        rc = ctx.match_nn_noalloc(big.data_ptr(), 1025, big.data_ptr(), 8, out.data_ptr(), out.data_ptr(), out.data_ptr(),
-                                  out.data_ptr(), mode=pkg.MATCH_PLAIN)
+        big = hip.to_device(np.zeros((1025, 256), np.float32))
+        out = hip.to_device(np.zeros(1025, np.int32))
+        rc = ctx.match_nn_noalloc(big.value, 1025, big.value, 8, out.value, out.value, out.value, out.value, mode=pkg.MATCH_PLAIN)
         assert rc == pkg.PPG_ECAP and "exceed the fixed work memory" in ctx.last_error()
     finally:
+        hip.free_all()
         ctx.close()
