@@ -424,7 +424,7 @@ def main():
                            "descriptors within 1e-4, key points equal up to ties within 4e-5 in score; integer outputs are "
                            "not bit-exact against the CPU restatement, which only the fp32 mode is")
         split_bf16 = split_pass(1, "bf16x3",
-                                "the same step with ppg_config.precision = 1 (BASELINE config 3, 'bf16 conv / fp32 descriptors', in "
+                                "the same step with ppg_config.precision = 1 (the 'bf16 conv / fp32 descriptors' configuration, in "
                                 "its split form): the convolutions on the bf16 MFMA with operands split into bf16 hi + lo, three "
                                 "products, fp32 accumulate; descriptors within 1e-3 of the fp32 path, key-point sets equal up "
                                 "to near-ties; not bit-exact on the integer outputs")
