@@ -120,6 +120,52 @@ def test_ragged_sizes_vs_oracle(pkg, orc, onet, synth):
         assert float(np.linalg.norm(r["desc"] - d, axis=1).max()) < 1e-5
 
 
+def test_end_to_end_vs_oracle_random_scenes(pkg, orc, synth):
+    """Whole frames, image in -> key points, edges, adjacency, collinear pairs, descriptors out, against the oracle running
+    its own convolutions and its own libm, over a set of random sizes, scenes and JUNCTION_MAX_NUM values.  The two
+    evaluations differ by ~1e-6 in the score map (CPU and GPU exponentials), so a frame is compared exactly in its integer
+    outputs when no two competing scores are that close (nearly all frames) and by sets otherwise; scores 1e-5, edge
+    scores 1e-4, descriptors 1e-5."""
+    rng = np.random.default_rng(2024)
+    net = orc.Net()
+    cases = [(96, 128, "sparse", 500), (64, 96, "dense", 500)]
+    for _ in range(8):
+        cases.append((int(rng.integers(8, 31)) * 8, int(rng.integers(12, 41)) * 8, ("sparse", "dense")[int(rng.integers(0, 2))],
+                      (60, 500, 1024)[int(rng.integers(0, 3))]))
+    total_kp = total_edges = exact = 0
+    for k, (H, W, kind, maxnum) in enumerate(cases):
+        img = synth.make_frame(H, W, 3000 + k, int(rng.integers(0, 3)), kind)
+        ctx = pkg.Context(pkg.default_config(W, H, max_num=maxnum))
+        try:
+            r = ctx.extract(img)
+        finally:
+            ctx.close()
+        o = orc.extract(net, orc.default_cfg(W, H, maxnum), img)
+        tag = (H, W, kind, maxnum)
+        assert r["n"] == o["n"], tag
+        total_kp += r["n"]
+        total_edges += r["n_edges"]
+        if not np.array_equal(r["xy"], o["xy"]):
+            assert_keypoints_equivalent(r["xy"], r["score"], o["xy"], o["score"])
+            ea, eb = edge_coord_set(r["edge_idx"], r["xy"]), edge_coord_set(o["edge_idx"], o["xy"])
+            assert len(ea ^ eb) <= 2, (tag, len(ea ^ eb))
+            continue
+        assert float(np.abs(r["score"] - o["score"]).max(initial=0.0)) < 1e-5, tag
+        assert np.array_equal(r["un"], o["un"]) and np.array_equal(r["out"], o["out"]), tag
+        if not np.array_equal(r["edge_idx"], o["edge_idx"]):   # an edge score within rounding noise of a threshold
+            ea, eb = edge_coord_set(r["edge_idx"], r["xy"]), edge_coord_set(o["edge_idx"], o["xy"])
+            assert len(ea ^ eb) <= 2, (tag, len(ea ^ eb))
+            continue
+        assert np.allclose(r["edge_score"], o["edge_score"], rtol=0, atol=1e-4, equal_nan=True), tag
+        assert np.array_equal(r["conn_off"], o["conn_off"]) and np.array_equal(r["conn_idx"], o["conn_idx"]), tag
+        assert np.array_equal(r["coline_off"], o["coline_off"]) and np.array_equal(r["coline_pairs"], o["coline_pairs"]), tag
+        if r["n"]:
+            assert float(np.linalg.norm(r["desc"] - o["desc"], axis=1).max()) < 1e-5, tag
+        exact += 1
+    print(f"end to end: {exact} of {len(cases)} frames equal in every integer output, {total_kp} key points, {total_edges} edges")
+    assert exact >= len(cases) - 2 and total_kp > 600 and total_edges > 300
+
+
 def test_full_size_postprocessing_exact_on_gpu_tensors(pkg, orc, synth):
     """The benchmark image sizes: every integer output equals the oracle's when both start from the GPU's CNN tensors."""
     for (H, W, seed, kind, maxnum) in ((480, 640, 31, "sparse", 500), (480, 640, 32, "dense", 1024), (512, 512, 33, "dense", 1024),
