@@ -1114,8 +1114,9 @@ def test_waited_results_survive_the_next_submit(pkg, synth):
 def test_extend_map_matches_device_walk(pkg, orc, synth, monkeypatch):
     """The point-pair-graph matcher as one wave on the device against the oracle and against the host walk
     (PPG_EXTEND_HOST=1), on dense frames with many map points and edges; then a graph whose degrees exceed the
-    kernel's limits, which must fall back to the host walk and still agree; then wide windows (more than 64 key points
-    each) over a graph whose seeds have weight matrices of more than 64 entries."""
+    kernel's limits, which must fall back to the host walk and still agree (more listed map edges than the kernel holds);
+    then wide windows (more than 64 key points each) over a graph whose seeds have weight matrices of more than 64
+    entries; then few points with more than 64 edges each (the walk itself runs into the limit and hands over)."""
     H, W = 480, 640
     ctx = get_ctx(pkg, W, H, 1024)
     cfg = orc.default_cfg(W, H, 1024)
@@ -1124,9 +1125,11 @@ def test_extend_map_matches_device_walk(pkg, orc, synth, monkeypatch):
     host = pkg.Context(pkg.default_config(W, H, max_num=1024))
     monkeypatch.delenv("PPG_EXTEND_HOST")
     rng = np.random.default_rng(15)
-    for trial, (m, nedges, th) in enumerate(((800, 1500, 4.0), (1500, 4000, 7.0), (300, 9000, 10.0), (300, 5000, 40.0))):
+    for trial, (m, nedges, th) in enumerate(((800, 1500, 4.0), (1500, 4000, 7.0), (300, 9000, 10.0), (300, 5000, 40.0), (150, 4000, 10.0))):
         g = random_map_graph(rng, r["desc"], r["un"], min(m, r["n"]), nedges)
         mm = g["desc"].shape[0]
+        if trial == 4:   # inside the kernel's array sizes, beyond its edges per point
+            assert g["edge_off"][-1] <= 16384 and np.diff(g["edge_off"]).max() > 64
         tracked = (rng.random(mm) < 0.05).astype(np.uint8)
         fmp = np.full(r["n"], -1, np.int32)
         pre = rng.choice(r["n"], size=40, replace=False)
