@@ -942,7 +942,7 @@ static int create_impl(ppg_ctx* c) {
     c->mask_words = (c->maxn + 255) / 256 * 4;
     DA(pair_mask, B * (size_t)c->maxn * c->mask_words);
     DA(lt_geo, B * c->tail_cap * 3);
-    DA(lt_col_off, B * (c->maxn + 1));
+    DA(lt_col_off, (B * (c->maxn + 1) + 63) / 64 * 64);   // (cleared in whole 256-byte units: one fill kernel, see launch_line_tail)
     DA(lt_col_cur, B * c->maxn);
     DA(lt_col_ent, B * c->tail_cap * 4);
     DA(lt_pairs, B * (size_t)c->pair_cap * 2);

@@ -2373,7 +2373,9 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
 
 hipError_t launch_line_tail(const LineTailArgs& a, hipStream_t s) {
     if (a.max_num > LT_MAXPTS || a.tail_cap > 65536 || a.tail_cap < 2 * a.edge_cap + 2) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(a.col_off, 0, sizeof(int) * (size_t)a.B * (a.max_num + 1), s);
+    // (the array is allocated in whole 256-byte units: a size that is no multiple of sixteen bytes would make the runtime
+    // split the clear into two fill kernels, 5 us more on the chain a one-frame call waits for)
+    hipError_t e = hipMemsetAsync(a.col_off, 0, (sizeof(int) * (size_t)a.B * (a.max_num + 1) + 255) / 256 * 256, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(line_geo_kernel, dim3(32, a.B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(line_col_scan_kernel, dim3(a.B), dim3(1024), 0, s, a);
