@@ -942,7 +942,8 @@ static int create_impl(ppg_ctx* c) {
     c->mask_words = (c->maxn + 255) / 256 * 4;
     DA(pair_mask, B * (size_t)c->maxn * c->mask_words);
     DA(lt_geo, B * c->tail_cap * 3);
-    DA(lt_col_off, (B * (c->maxn + 1) + 63) / 64 * 64);   // (cleared in whole 256-byte units: one fill kernel, see launch_line_tail)
+    DA(lt_col_off, B * (c->maxn + 1));
+    HIPCHK(c, hipMemset(c->lt_col_off, 0, sizeof(int) * B * (c->maxn + 1)));   // (line_resolve_kernel leaves it zeroed after every use)
     DA(lt_col_cur, B * c->maxn);
     DA(lt_col_ent, B * c->tail_cap * 4);
     DA(lt_pairs, B * (size_t)c->pair_cap * 2);
@@ -1146,9 +1147,11 @@ int ppg_detect_keypoints(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    // the slot's counters are cleared before the stream waits for the networks: the clear then runs beside them instead
+    // of on the chain behind the junction logits (the slot is free: its last batch was waited for)
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(int) * 8 * n, c->post));
     HIPCHK(c, hipStreamWaitEvent(c->post, early_post(c, n) ? c->slot[c->cur].junc_done : c->slot[c->cur].cnn_done, 0));
     ProfScope ps(c, PPG_PROF_POST, c->post);
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(int) * 8 * n, c->post));
     ppg::NmsArgs a = nms_args(c, n);
     if (!c->skip_score) HIPCHK(c, ppg::launch_score_map(a, c->post));
     HIPCHK(c, ppg::launch_nms(a, c->post));

@@ -2190,6 +2190,9 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
     const int n = cnt[3], nc = cnt[2];
     int32_t* conn_off = a.conn_off + (size_t)b * (a.max_num + 1);
     int32_t* coline_off = a.coline_off + (size_t)b * (a.max_num + 1);
+    // The per-point counts that line_geo_kernel accumulates (col_off) were last read by line_inter_kernel: this frame's row
+    // goes back to zero here for the next batch, which spares the chain a clearing launch (the array starts zeroed).
+    for (int p = tid; p <= a.max_num; p += 1024) a.col_off[(size_t)b * (a.max_num + 1) + p] = 0;
     if (n == 0 || nc == 0) {
         // PPGExtractor.cpp:239-240 returns early without key points; without candidates every list is empty
         for (int p = tid; p <= n; p += 1024) { conn_off[p] = 0; coline_off[p] = 0; }
@@ -2373,10 +2376,6 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
 
 hipError_t launch_line_tail(const LineTailArgs& a, hipStream_t s) {
     if (a.max_num > LT_MAXPTS || a.tail_cap > 65536 || a.tail_cap < 2 * a.edge_cap + 2) return hipErrorInvalidValue;
-    // (the array is allocated in whole 256-byte units: a size that is no multiple of sixteen bytes would make the runtime
-    // split the clear into two fill kernels, 5 us more on the chain a one-frame call waits for)
-    hipError_t e = hipMemsetAsync(a.col_off, 0, (sizeof(int) * (size_t)a.B * (a.max_num + 1) + 255) / 256 * 256, s);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(line_geo_kernel, dim3(32, a.B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(line_col_scan_kernel, dim3(a.B), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(line_col_fill_kernel, dim3(32, a.B), dim3(256), 0, s, a);
