@@ -1064,6 +1064,8 @@ int ppg_write_tensor(ppg_ctx* c, int which, int frame, const float* src, size_t 
     return PPG_OK;
 }
 
+bool early_post(const ppg_ctx* c, int n);
+
 int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     if (!c) return PPG_EINVAL;
     if (!imgs || n < 1 || n > c->B) return fail(c, PPG_EINVAL, "ppg_inference: n = %d outside 1..%d", n, c->B);
@@ -1119,11 +1121,11 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     // PointHeatmap (junction_decoder.py:14-15)
     RC(run_heads(c, n, H / 8, W / 8));  // convPa + convDa + EdgeHeatmap block 0
     RC(run_conv(c, c->pb, c->pa_o, c->junc, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
-    HIPCHK(c, hipEventRecord(c->slot[c->cur].junc_done, c->stream));
+    if (early_post(c, n)) HIPCHK(c, hipEventRecord(c->slot[c->cur].junc_done, c->stream));
     // EdgeHeatmap (heatmap_decoder.py:19-22); the last 1x1 conv runs in ppg_detect_lines' first kernel
     RC(run_conv(c, c->h1, c->hs0, c->hs1, n, H / 4, W / 4, ppg::CONV_PS2, 1));
     RC(run_conv(c, c->h2, c->hs1, c->hs2, n, H / 2, W / 2, ppg::CONV_PS2, 1));
-    HIPCHK(c, hipEventRecord(c->slot[c->cur].heat_done, c->stream));
+    if (early_post(c, n)) HIPCHK(c, hipEventRecord(c->slot[c->cur].heat_done, c->stream));
     // Descriptor (descriptor_decoder.py:14-15)
     RC(run_conv(c, c->db, c->da_o, c->descmap, n, H / 8, W / 8, ppg::CONV_PLAIN, 0));
 #undef RC
