@@ -1008,6 +1008,9 @@ int ppgo_extend_map_matches(const ppgo_cfg* c, float nnratio, float th, const pp
             else if (d < best2) best2 = d;
         }
         if (best > TH_HIGH && best > nnratio * best2) continue;
+        // every candidate of the window was skipped and nnratio >= 1 lets 1e6 > nnratio * 1e6 fail: the reference indexes
+        // with -1 here (Matcher.cpp:279, undefined behaviour); the library and this statement skip the map point
+        if (bestIdx < 0) continue;
         frame_mp[bestIdx] = mp;
         tracked[mp] = 1;
         nmatches++;

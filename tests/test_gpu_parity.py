@@ -622,6 +622,51 @@ def test_extend_map_matches_vs_oracle(pkg, orc, synth):
         assert co > 50 and (eo >= 0).sum() > 0
 
 
+def test_extend_map_matches_fuzz(pkg, orc, synth):
+    """Many small random problems for the point-pair-graph matcher, with the degenerate shapes a real map can hold: map edges
+    from a point to itself, repeated edges, missing other ends, points without edges, everything pre-tracked or nothing,
+    slots pre-assigned to bad or unobserved points, windows of every size including none, nnratio above and below 1."""
+    H, W = 240, 320
+    ctx = get_ctx(pkg, W, H, 500)
+    cfg = orc.default_cfg(W, H, 500)
+    r = ctx.extract(synth.make_frame(H, W, 77, 0, "dense"))
+    n = r["n"]
+    assert n > 150 and r["n_edges"] > 50
+    rng = np.random.default_rng(4242)
+    hits = 0
+    for trial in range(40):
+        m = int(rng.integers(1, 180))
+        g = random_map_graph(rng, r["desc"], r["un"], min(m, n), int(rng.integers(0, 4 * m + 1)),
+                             r["edge_idx"] if trial % 3 == 0 else None)
+        m = g["desc"].shape[0]
+        ne = len(g["edge_other"])
+        if ne:
+            # self-loops and repeated other ends
+            owner = np.repeat(np.arange(m), np.diff(g["edge_off"]))
+            loops = rng.random(ne) < 0.05
+            g["edge_other"][loops] = owner[loops]
+            dup = rng.random(ne) < 0.1
+            g["edge_other"][dup] = int(rng.integers(0, m))
+        g["in_view"] = (rng.random(m) < rng.uniform(0.3, 1.0)).astype(np.uint8)
+        g["bad"] = (rng.random(m) < rng.uniform(0.0, 0.3)).astype(np.uint8)
+        g["nobs"] = rng.integers(0, 2, m).astype(np.int32) * rng.integers(0, 4, m).astype(np.int32)
+        mode = trial % 4
+        tracked = (np.ones(m) if mode == 1 else rng.random(m) < (0.0 if mode == 0 else 0.3)).astype(np.uint8)
+        fmp = np.full(n, -1, np.int32)
+        k = int(rng.integers(0, n // 2))
+        if k:
+            fmp[rng.choice(n, size=k, replace=False)] = rng.integers(0, m, k)
+        fme = np.full(r["n_edges"], -1, np.int32)
+        th = float(rng.choice([0.5, 2.0, 5.0, 15.0, 60.0]))
+        ratio = float(rng.choice([0.6, 0.9, 1.2]))
+        args = (ratio, th, g, r["desc"], r["un"], r["edge_idx"], r["conn_off"], r["conn_idx"], tracked, fmp, fme)
+        co, to, po, eo = orc.extend_map_matches(cfg, *args)
+        cg, tg, pg, eg = ctx.extend_map_matches(*args)
+        assert cg == co and np.array_equal(tg, to) and np.array_equal(pg, po) and np.array_equal(eg, eo), (trial, m, ne, th, ratio)
+        hits += co
+    assert hits > 500
+
+
 def test_host_mirror_program(pkg, synth, tmp_path):
     """The C++ mirror (PPGExtractor::run + Matcher::SearchForInitialization) gives what the C ABI gives."""
     import os
