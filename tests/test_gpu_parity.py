@@ -667,6 +667,65 @@ def test_extend_map_matches_fuzz(pkg, orc, synth):
     assert hits > 500
 
 
+def test_match_projected_fuzz(pkg, orc):
+    """The windowed search shared by SearchByProjection and Fuse (candidate lists from the grid, first argmin, threshold
+    and ratio, accepted rows claiming their slot: a fixed-point iteration on the device) against the sequential pass
+    written out here row by row, the distances of every window taken from the oracle's chain: random windows (none to
+    everything), ties, blocked slots, rows that do not claim, rows switched off, the reprojection gate."""
+    import ctypes as C
+    W, H = 640, 480
+    ctx = get_ctx(pkg, W, H)
+    rng = np.random.default_rng(99)
+    total = 0
+    for trial in range(25):
+        n1, n2 = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        B = unit_rows(rng, n2)
+        src = rng.integers(0, n2, n1)
+        A = B[src] + float(rng.choice([0.05, 0.3, 1.0])) * rng.normal(size=(n1, 256)).astype(np.float32) / 16
+        A = (A / np.linalg.norm(A, axis=1, keepdims=True)).astype(np.float32)
+        if n2 > 4:
+            B[3] = B[1]                      # exact ties: the first candidate in window order wins
+        pos2 = np.stack([rng.uniform(0, W - 1, n2), rng.uniform(0, H - 1, n2)], 1).astype(np.float32)
+        uv = (pos2[src] + rng.uniform(-12, 12, (n1, 2))).astype(np.float32)
+        radius = rng.choice([0.0, 3.0, 10.0, 40.0, 1000.0], n1).astype(np.float32)
+        row_ok = (rng.random(n1) < 0.9).astype(np.uint8) if trial % 2 else None
+        claims = (rng.random(n1) < 0.7).astype(np.uint8) if trial % 3 else None
+        blocked = (rng.random(n2) < 0.2).astype(np.uint8) if (trial % 3 or trial % 5 == 0) else None
+        th = float(rng.choice([0.3, 0.7, 0.8, 2.0]))
+        ratio = float(rng.choice([0.0, 0.6, 0.9]))
+        e2 = float(rng.choice([-1.0, 36.0]))
+        cnt, bi, bd, blk = ctx.match_projected(pos2, B, A, uv, radius, th, ratio, row_ok, claims, blocked, e2)
+        # the sequential pass
+        state = blocked.copy() if blocked is not None else np.zeros(n2, np.uint8)
+        want_i, want_d, nm = np.full(n1, -1, np.int32), np.full(n1, 1e6, np.float32), 0
+        for i in range(n1):
+            if row_ok is not None and not row_ok[i]:
+                continue
+            cand = ctx.features_in_area(pos2, float(uv[i, 0]), float(uv[i, 1]), float(radius[i]))
+            if e2 >= 0:
+                d2 = (np.float32(uv[i, 0]) - pos2[cand, 0]) ** 2 + (np.float32(uv[i, 1]) - pos2[cand, 1]) ** 2
+                cand = cand[~(d2 > np.float32(e2))]
+            cand = np.ascontiguousarray(cand, np.int32)
+            b, s2 = C.c_float(), C.c_float()
+            j = orc.lib().ppgo_window_nn(A[i].ctypes.data_as(C.c_void_p), 256, B.ctypes.data_as(C.c_void_p),
+                                         cand.ctypes.data_as(C.c_void_p), len(cand), state.ctypes.data_as(C.c_void_p),
+                                         C.byref(b), C.byref(s2))
+            want_d[i] = b.value
+            if b.value <= th and not (ratio > 0 and b.value > np.float32(ratio) * np.float32(s2.value)):
+                want_i[i] = j
+                nm += 1
+                if claims is not None and blocked is not None and claims[i]:
+                    state[j] = 1
+        tag = (trial, n1, n2, th, ratio, e2)
+        assert np.array_equal(bi, want_i), tag
+        assert np.array_equal(bd, want_d), tag
+        assert cnt == nm, tag
+        if blocked is not None and claims is not None:
+            assert np.array_equal(blk, state), tag
+        total += nm
+    assert total > 500
+
+
 def test_host_mirror_program(pkg, synth, tmp_path):
     """The C++ mirror (PPGExtractor::run + Matcher::SearchForInitialization) gives what the C ABI gives."""
     import os
