@@ -726,6 +726,55 @@ def test_match_projected_fuzz(pkg, orc):
     assert total > 500
 
 
+def test_match_nn_claim_mode_fuzz(pkg, orc):
+    """ppg_match_nn in its claim mode (the loop of SearchForInitialization) over random candidate lists: empty rows, rows
+    with fewer and with many more than eight candidates, a candidate listed twice, skipped columns, clustered descriptors
+    (most rows find their nearest columns taken), against the sequential pass written out here."""
+    import ctypes as C
+    ctx = get_ctx(pkg, 640, 480)
+    rng = np.random.default_rng(123)
+    total = 0
+    for trial in range(25):
+        nA, nB = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        k = int(rng.integers(1, 12))
+        base = unit_rows(rng, k)
+        mk = lambda n: base[rng.integers(0, k, n)] + float(rng.choice([0.02, 0.2])) * rng.normal(size=(n, 256)).astype(np.float32) / 16
+        A, B = mk(nA), mk(nB)
+        A = (A / np.linalg.norm(A, axis=1, keepdims=True)).astype(np.float32)
+        B = (B / np.linalg.norm(B, axis=1, keepdims=True)).astype(np.float32)
+        off, idx = [0], []
+        for i in range(nA):
+            c = int(rng.choice([0, 1, 3, 8, 9, 40, nB]))
+            c = min(c, nB)
+            row = list(rng.choice(nB, size=c, replace=False)) if c else []
+            if len(row) > 2 and rng.random() < 0.3:
+                row.append(row[0])              # the same column listed twice
+            idx += row
+            off.append(len(idx))
+        off = np.array(off, np.int32)
+        idx = np.array(idx if idx else [0], np.int32)
+        skip = (rng.random(nB) < 0.15).astype(np.uint8) if trial % 2 else None
+        th, ratio = float(rng.choice([0.3, 0.7, 2.0])), float(rng.choice([0.8, 0.95, 1.1]))
+        m, best, second, cnt = ctx.match_nn(A, B, off, idx, skip, th=th, ratio=ratio, mode=pkg.MATCH_INIT)
+        state = skip.copy() if skip is not None else np.zeros(nB, np.uint8)
+        want = np.full(nA, -1, np.int32)
+        nm = 0
+        for i in range(nA):
+            cand = np.ascontiguousarray(idx[off[i]:off[i + 1]], np.int32)
+            b, s2 = C.c_float(), C.c_float()
+            j = orc.lib().ppgo_window_nn(A[i].ctypes.data_as(C.c_void_p), 256, B.ctypes.data_as(C.c_void_p),
+                                         cand.ctypes.data_as(C.c_void_p), len(cand), state.ctypes.data_as(C.c_void_p),
+                                         C.byref(b), C.byref(s2))
+            assert (best[i], second[i]) == (np.float32(b.value), np.float32(s2.value)), (trial, i)
+            if j >= 0 and b.value <= th and np.float32(b.value) < np.float32(s2.value) * np.float32(ratio):   # Matcher.cpp:630
+                want[i] = j
+                state[j] = 1
+                nm += 1
+        assert np.array_equal(m, want) and cnt == nm, (trial, nA, nB, th, ratio)
+        total += nm
+    assert total > 300
+
+
 def test_host_mirror_program(pkg, synth, tmp_path):
     """The C++ mirror (PPGExtractor::run + Matcher::SearchForInitialization) gives what the C ABI gives."""
     import os
