@@ -775,6 +775,52 @@ def test_match_nn_claim_mode_fuzz(pkg, orc):
     assert total > 300
 
 
+def test_nms_fuzz_adversarial_score_maps(pkg, orc):
+    """Greedy radius-4 NMS as a fixed point on the device against the oracle's sorted sequential pass, on score maps made
+    to be hard: plateaus of equal scores (the order of ties is y*W + x), values quantised to a few levels, checkerboards,
+    ridges, everything above the threshold, peaks on the four-pixel border, and caps from 1 to more than the survivors."""
+    rng = np.random.default_rng(31)
+    n_total = 0
+    for trial in range(24):
+        H, W = [(96, 128), (120, 160), (64, 200), (240, 320)][trial % 4]
+        kind = trial % 6
+        if kind == 0:
+            sc = np.full((H, W), 0.5, np.float32)                                  # one plateau
+        elif kind == 1:
+            sc = (rng.integers(0, 4, (H, W)) / 4.0).astype(np.float32)             # four levels: ties everywhere
+        elif kind == 2:
+            yy, xx = np.mgrid[0:H, 0:W]
+            sc = (((yy // 3 + xx // 3) % 2) * 0.7 + 0.01 * rng.random((H, W))).astype(np.float32)
+        elif kind == 3:
+            sc = np.zeros((H, W), np.float32)                                      # ridges of equal height
+            sc[::7, :] = 0.6
+            sc[:, ::11] = 0.6
+        elif kind == 4:
+            sc = rng.random((H, W)).astype(np.float32)                             # everything is a candidate
+        else:
+            sc = np.zeros((H, W), np.float32)                                      # sparse peaks, some inside the border band
+            for _ in range(300):
+                sc[int(rng.integers(0, H)), int(rng.integers(0, W))] = float(rng.choice([0.3, 0.3, 0.9, rng.random()]))
+        cap = int(rng.choice([1, 7, 60, 500, 1024]))
+        ctx = pkg.Context(pkg.default_config(W, H, max_num=cap))
+        try:
+            ctx.inference([np.zeros((H, W), np.uint8)])
+            ctx.write_tensor(pkg.T_SCORE, sc)
+            ctx.detect_keypoints(1)
+            ctx.detect_lines(1)
+            ctx.gen_descriptors(1)
+            r = ctx.collect(1)[0]
+        finally:
+            ctx.close()
+        o = orc.detect_keypoints(orc.default_cfg(W, H, cap), sc)
+        tag = (trial, H, W, kind, cap)
+        assert r["n"] == o["n"], tag
+        assert np.array_equal(r["xy"], o["xy"]) and np.array_equal(r["score"], o["score"]), tag
+        assert np.array_equal(r["un"], o["un"]) and np.array_equal(r["out"], o["out"]), tag
+        n_total += r["n"]
+    assert n_total > 2000
+
+
 def test_host_mirror_program(pkg, synth, tmp_path):
     """The C++ mirror (PPGExtractor::run + Matcher::SearchForInitialization) gives what the C ABI gives."""
     import os
