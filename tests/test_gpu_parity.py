@@ -821,6 +821,70 @@ def test_nms_fuzz_adversarial_score_maps(pkg, orc):
     assert n_total > 2000
 
 
+def test_line_graph_fuzz_drawn_wireframes(pkg, orc):
+    """refineHeatMap + detectLines on the device against the oracle on injected maps: random wireframes (key points as
+    score peaks, the heat map drawn along random segments between them, with noise and gaps), which make for many
+    candidates that overlap at shared end points, collinear continuations through a point, short edges and stars of many
+    lines at one point.  Every integer output must be equal, the edge scores bit for bit."""
+    rng = np.random.default_rng(57)
+    edges_total = coline_total = 0
+    for trial in range(12):
+        H, W = [(240, 320), (200, 264), (480, 640)][trial % 3]
+        npts = int(rng.choice([12, 40, 120, 300]))
+        pts = np.stack([rng.integers(6, W - 6, npts), rng.integers(6, H - 6, npts)], 1)
+        if trial % 2:                                              # points on common lines: collinear pairs
+            for k in range(0, npts - 2, 3):
+                t = rng.uniform(0.3, 0.7)
+                pts[k + 2] = np.round(pts[k] + t * (pts[k + 1] - pts[k])).astype(int)
+        score = np.zeros((H, W), np.float32)
+        for k, (x, y) in enumerate(pts):
+            score[y, x] = 0.5 + 0.4 * rng.random()
+        heat = (0.05 * rng.random((H, W))).astype(np.float32)
+        nseg = int(npts * rng.uniform(0.8, 2.5))
+        for _ in range(nseg):
+            a, b = rng.choice(npts, 2, replace=False)
+            if trial % 4 == 0 and rng.random() < 0.5:
+                a = 0                                              # a star around the first point
+            (x0, y0), (x1, y1) = pts[a], pts[b]
+            L = int(max(abs(x1 - x0), abs(y1 - y0))) + 1
+            xs = np.round(np.linspace(x0, x1, L)).astype(int)
+            ys = np.round(np.linspace(y0, y1, L)).astype(int)
+            v = (0.6 + 0.4 * rng.random(L)).astype(np.float32)
+            if rng.random() < 0.3:
+                g0 = int(rng.integers(0, L))
+                v[g0:g0 + int(rng.integers(1, 6))] = 0.0           # a gap
+            heat[ys, xs] = np.maximum(heat[ys, xs], v)
+            heat[np.clip(ys + 1, 0, H - 1), xs] = np.maximum(heat[np.clip(ys + 1, 0, H - 1), xs], 0.5 * v)
+        cap = 500
+        ctx = pkg.Context(pkg.default_config(W, H, max_num=cap))
+        try:
+            ctx.inference([np.zeros((H, W), np.uint8)])
+            ctx.write_tensor(pkg.T_SCORE, score)
+            ctx.write_tensor(pkg.T_HEAT, heat)
+            ctx.detect_keypoints(1)
+            ctx.detect_lines(1)
+            ctx.gen_descriptors(1)
+            r = ctx.collect(1)[0]
+            refined = ctx.read_tensor(pkg.T_HEAT_REFINED)
+        finally:
+            ctx.close()
+        cfg = orc.default_cfg(W, H, cap)
+        kp = orc.detect_keypoints(cfg, score)
+        assert np.array_equal(r["xy"], kp["xy"])
+        ref_o = orc.refine_heat(cfg, heat)
+        assert np.array_equal(refined, ref_o), trial
+        ln = orc.detect_lines(cfg, ref_o, kp["un"], kp["out"])
+        tag = (trial, H, W, npts, nseg)
+        assert np.array_equal(r["edge_idx"], ln["edge_idx"]), tag
+        assert np.array_equal(r["edge_score"], ln["edge_score"], equal_nan=True), tag
+        assert np.array_equal(r["conn_off"], ln["conn_off"][:r["n"] + 1]) and np.array_equal(r["conn_idx"], ln["conn_idx"][:len(r["conn_idx"])]), tag
+        assert np.array_equal(r["coline_pairs"], ln["coline_pairs"][:len(r["coline_pairs"])]), tag
+        edges_total += r["n_edges"]
+        coline_total += len(r["coline_pairs"])
+    print(f"wireframes: {edges_total} edges, {coline_total} collinear pairs")
+    assert edges_total > 300 and coline_total > 10
+
+
 def test_host_mirror_program(pkg, synth, tmp_path):
     """The C++ mirror (PPGExtractor::run + Matcher::SearchForInitialization) gives what the C ABI gives."""
     import os
