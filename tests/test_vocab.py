@@ -106,3 +106,33 @@ def test_bow_transform_vs_oracle(pkg, orc, synth, tmp_path):
     finally:
         ctx.close()
         v.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,L", [(2, 5), (3, 4), (10, 2), (20, 2), (17, 1), (9, 3)])
+def test_bow_transform_tree_shapes(k, L, pkg, orc, tmp_path):
+    """Tree descent on the GPU against the oracle for other branching factors and depths than the shipped 9 x 3: more
+    children than the sixteen lanes that share a node, a single level, deep narrow trees; every levelsup from the leaves
+    to above the root; descriptors equal to a node's own (distance zero) and far from all."""
+    from oracle import vocab as ov
+    path = str(tmp_path / f"voc_{k}_{L}.bin")
+    ov.write_synthetic(path, k=k, L=L, dim=256, seed=100 * k + L)
+    o = ov.load(path)
+    v = pkg.Vocabulary(path)
+    ctx = pkg.Context(pkg.default_config(128, 96))
+    try:
+        rng = np.random.default_rng(k * 31 + L)
+        d = rng.normal(size=(300, 256)).astype(np.float32)
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        nodes = np.asarray(o["desc"] if isinstance(o, dict) else o.desc, np.float32).reshape(-1, 256)
+        take = rng.integers(1, nodes.shape[0], 60)
+        d[:60] = nodes[take]                       # exactly a node's descriptor
+        d[60:80] *= 40.0                           # far from everything
+        for levelsup in range(0, L + 2):
+            hw, hwt, hnd = pkg.bow_transform(ctx, v, d, levelsup)
+            ow, owt, ond = orc.bow_transform(o, d, levelsup)
+            assert np.array_equal(hw, ow) and np.array_equal(hwt, owt) and np.array_equal(hnd, ond), (k, L, levelsup)
+        assert len(set(hw.tolist())) > min(k ** L, 300) // 8
+    finally:
+        ctx.close()
+        v.close()
