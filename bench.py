@@ -282,7 +282,40 @@ def main():
             host[t, s] = synth.frame_from_scene(scene, H, W, t)
     frames = torch.from_numpy(host).cuda()
     streams_mod = importlib.import_module("ppg_slam_amd.streams")
-    shutter = streams_mod.ShutterBarrier(dist, "cuda", single_rank_too=force_dist)
+    # The global-shutter barrier runs behind the library's C entry points (ppg_shutter_*: RCCL called from C on a stream
+    # of the library's own); torch.distributed only carries the 128-byte communicator id to the ranks and the harness's
+    # own barrier / max-over-ranks.  If the C entry points cannot be set up on every rank, all ranks fall back to the
+    # same protocol over torch.distributed, and the line says so.
+    shutter, shutter_kind = None, "none (one rank)"
+    if dist is not None:
+        try:
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid[0] = streams_mod.shutter_unique_id()
+                except Exception as e:   # noqa: BLE001
+                    uid[0] = "error: " + str(e)[:200]
+            dist.broadcast_object_list(uid, src=0)
+            if not isinstance(uid[0], bytes):
+                raise RuntimeError(str(uid[0]))
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            why = ""
+            try:
+                shutter = streams_mod.Shutter(ctx, rank, world, uid[0])
+            except Exception as e:   # noqa: BLE001
+                ok.zero_()
+                why = str(e)[:200]
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) != 1:
+                if shutter is not None:
+                    shutter.close()
+                shutter = None
+                raise RuntimeError(why or "another rank could not create its shutter")
+            shutter_kind = "ppg_shutter_* (C ABI, RCCL all-reduce(MIN) of an int32 on the library's stream)"
+        except Exception as e:   # noqa: BLE001
+            shutter_kind = "torch.distributed all_reduce(MIN) (fall-back: %s)" % str(e)[:200]
+    if shutter is None:
+        shutter = streams_mod.ShutterBarrier(dist, "cuda", single_rank_too=force_dist)
 
     def barrier():
         torch.cuda.synchronize()
@@ -395,7 +428,7 @@ def main():
 
     # Fourth pass (fp32 runs only): the same step with the 3x3 convolutions in the fp16 hi/lo-split mode
     # (ppg_config.precision = 3), reported beside the number of record, never as it.
-    split, split_bf16 = None, None
+    split, split_bf16, plain_bf16 = None, None, None
     if args.precision == 0 and not args.no_split_pass:
         do_match[0] = True
 
@@ -428,6 +461,11 @@ def main():
                                 "its split form): the convolutions on the bf16 MFMA with operands split into bf16 hi + lo, three "
                                 "products, fp32 accumulate; descriptors within 1e-3 of the fp32 path, key-point sets equal up "
                                 "to near-ties; not bit-exact on the integer outputs")
+        plain_bf16 = split_pass(2, "bf16",
+                                "the same step with ppg_config.precision = 2 (the 'bf16 conv / fp32 descriptors' configuration, "
+                                "taken literally): plain bf16 operands, one product, fp32 accumulate.  OUTSIDE the parity bar - "
+                                "descriptor L2 error up to 5e-2 against the fp32 path, a few per cent of the key points differ - "
+                                "and reported for that deviation only, never as the number of record")
 
     if rank == 0:
         dom_ms, dom_launches = prof["conv1a"]
@@ -477,20 +515,32 @@ def main():
             "matchers_ms": matchers,
             "f16_split_mode": split,
             "bf16_split_mode": split_bf16,
+            "plain_bf16_mode": plain_bf16,
+            "shutter": shutter_kind,
+            "value_input": "images resident in HBM when the timed region starts; `with_upload` is the same step with every "
+                           "image handed over in host memory (PCIe-inclusive)",
             "device_ms_note": f"from a second pass of {nb} steps with events around every kernel class (not the timed region)",
         }
+        # HBM bytes per launch of the dominant kernel come from hardware counters, which only a profiler run can read:
+        # profiles/traffic.json holds them per arithmetic mode (rocprofv3 --pmc passes of this very command,
+        # tools/collect_profiles.sh); the line says where the figure is from.
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
             try:
                 tj = json.load(open(tr))
-                if tj.get("batch") == B and tj.get("width") == W and tj.get("height") == H and \
-                        tj.get("precision", 0) == args.precision:
-                    out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                ent = tj.get("by_precision", {}).get(str(args.precision))
+                if ent and tj.get("batch") == B and tj.get("width") == W and tj.get("height") == H:
+                    out["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = "profiles/traffic.json: " + tj.get("method", "rocprofv3 --pmc passes") + \
+                        " - read from that file, not measured by this run"
+                    out["roofline"]["algorithmic_bytes_per_launch"] = ent.get("algorithmic_bytes_per_launch")
             except Exception:
                 pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W, args.kind, args.max_num)
         print(json.dumps(out), flush=True)
+    if hasattr(shutter, "close"):
+        shutter.close()
     ctx.close()
     if dist is not None:
         dist.barrier()

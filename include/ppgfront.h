@@ -27,6 +27,7 @@ extern "C" {
 #define PPG_ENOMEM (-4)
 #define PPG_ECAP (-5)     /* a capacity given at create time was exceeded */
 #define PPG_ERANGE (-6)   /* precision 3: an activation left the range of the fp16 split (use precision 0 or 1) */
+#define PPG_ECOMM (-7)    /* RCCL could not be loaded, or one of its calls failed (multi-GPU mode) */
 
 typedef struct ppg_ctx ppg_ctx;
 
@@ -73,6 +74,23 @@ void ppg_default_config(ppg_config* cfg, int width, int height);
 ppg_ctx* ppg_create(const ppg_config* cfg);
 void ppg_destroy(ppg_ctx* ctx);
 const char* ppg_last_error(const ppg_ctx* ctx);
+
+/* A context for matching only.  The reference builds a Matcher on the stack wherever it needs one, in three threads at
+ * once (tracking: system/src/Tracking.cpp:524, 761, 803, 992; local mapping: system/src/LocalMapping.cpp:214; loop
+ * closing: system/src/LoopClosing.cpp:408-409, 786, 1061); a context is not thread-safe, so each of those threads owns
+ * one.  This kind loads no weights, allocates no network or frame buffers and does no warm-up: it costs five streams and
+ * a few bytes until its first call grows the matcher's work arrays.  Of cfg it reads width, height, K, D, fisheye (the
+ * image bounds of the frame grid), device_id and junction_max_num.  Every matching/ entry point, the grid, the
+ * vocabulary transform of host descriptors and ppg_match_nn_noalloc work on it; the extractor's entry points and the
+ * ones that use resident frames (ppg_match_frames, ppg_match_prev_batch, ppg_bow_transform_batch) return PPG_EINVAL. */
+ppg_ctx* ppg_create_matcher(const ppg_config* cfg);
+
+/* The ten tunables are public mutable statics that the reference reads on every frame (feature/include/PPGExtractor.h:
+ * 105-114).  This call applies the ones that do not size a buffer — junction_thresh, line_valid_thresh,
+ * line_valid_ratio, line_dist_thresh, heatmap_refine_sz, line_heatmap_thresh, line_inlier_rate — from cfg to the next
+ * frames, without touching weights or buffers.  A cfg whose desc_dim, junction_nms_radius or junction_max_num differs
+ * from the context's returns PPG_ECAP (those need a new context); pending batches must have been waited for. */
+int ppg_set_tunables(ppg_ctx* ctx, const ppg_config* cfg);
 
 /* Results of PPGExtractor::run for one frame (PPGExtractor.cpp:118-147) as structure-of-arrays.
  * Buffers are owned by the context and stay valid until the next extract call on it.
@@ -192,8 +210,12 @@ int ppg_match_nn(ppg_ctx* ctx, const float* A, int nA, const float* B, int nB, i
  * device array inside the library that every GPU holds until the process ends, so nA and nB are limited to
  * PPG_NOALLOC_MAX_ROWS (PPG_ECAP beyond that; ppg_match_nn has no such limit).  The call allocates and frees nothing.
  * stream: a hipStream_t (as void*) to enqueue on, without waiting — or NULL: the context's own stream, and the call
- * returns when the results are in place.  All calls on one GPU share the one work array: calls that overlap on a GPU
- * (two contexts, two streams, two threads) race; serialise them. */
+ * returns when the results are in place.  All calls on one GPU share the one work array, and the library orders them:
+ * host threads take a per-GPU lock for the duration of the call (a call on the context's own stream holds it until its
+ * results are in place), and a call on another stream than the one before it first makes its stream wait for an event
+ * recorded behind that call, so two contexts, streams or threads never use the array at once.  The one exception is a
+ * stream under graph capture: no event can tie a captured call to work outside its graph, so launches of such a graph
+ * must not overlap other calls on that GPU. */
 #define PPG_NOALLOC_MAX_ROWS 1024
 int ppg_match_nn_noalloc(ppg_ctx* ctx, const float* dA, int nA, const float* dB, int nB, int dim,
                          float th, float ratio, int mode,
@@ -375,6 +397,42 @@ int ppg_bow_vectors(const ppg_vocab* v, const int32_t* word_id, const double* we
  * round the other way, or when a frame exceeds its work arrays; PPG_LINES_HOST=1 sends every frame there).  No
  * counterpart in the reference. */
 int ppg_tail_stats(ppg_ctx* ctx, long long* frames, long long* host_frames);
+
+/* ---- multi-GPU mode: independent camera streams sharded over the GPUs of one node, one process (or thread) per GPU ----
+ * The reference is one process bound to one device (feature/src/PPGExtractor.cpp:41: torch::Device(torch::kCUDA, 0);
+ * one extractor, system/src/Tracking.cpp:51); these entry points are what replaces that hard-coded device when several
+ * cameras are extracted at once.  Streams never exchange activations.  The only collective is the global-shutter
+ * barrier: an all-reduce(MIN) over RCCL of each rank's newest finished frame group (4 bytes, latency-bound), so that
+ * the results of group k are released on every GPU together.  RCCL is loaded at the first of these calls (an RCCL image
+ * the process already maps is used; else PPG_RCCL_LIB; else librccl.so.1 of the ROCm installation).
+ *
+ *   rank 0:      ppg_shutter_unique_id(id); hand the 128 bytes to every rank (file, socket, launcher, ...)
+ *   every rank:  sh = ppg_shutter_create(ctx, rank, world, id)        collective: returns when all ranks have joined
+ *   per step:    ppg_wait_batch(...); ppg_shutter_release(sh, k, &released)   never waits for the collective
+ *   at the end:  ppg_shutter_drain(sh, &released); ppg_shutter_destroy(sh)
+ *
+ * ppg_shutter_release starts the all-reduce of `group` on a stream of the shutter's own (the result lands in pinned
+ * memory behind an event) and reports in *released the newest group known to be finished everywhere, which may lag by
+ * the barriers still in flight (at most eight; the ninth call waits for the oldest).  Every rank must call it the same
+ * number of times.  ppg_shutter_poll reads what has arrived without starting anything; ppg_shutter_drain waits for
+ * every barrier started.  A shutter belongs to the thread that drives its context. */
+typedef struct ppg_shutter ppg_shutter;
+#define PPG_SHUTTER_ID_BYTES 128
+int ppg_shutter_unique_id(uint8_t* id /* PPG_SHUTTER_ID_BYTES */);
+/* NULL on failure, reason in ppg_last_error(NULL).  ctx supplies the GPU and junction_max_num. */
+ppg_shutter* ppg_shutter_create(ppg_ctx* ctx, int rank, int world, const uint8_t* id);
+void ppg_shutter_destroy(ppg_shutter* sh);
+int ppg_shutter_release(ppg_shutter* sh, int group, int* released);
+int ppg_shutter_poll(ppg_shutter* sh, int* released);
+int ppg_shutter_drain(ppg_shutter* sh, int* released);
+/* barriers started so far and those whose result has not been read yet; either pointer may be NULL */
+int ppg_shutter_stats(const ppg_shutter* sh, long long* started, int* pending);
+/* A stereo rig split over two GPUs: swaps a frame's descriptors with rank `partner` (ncclSend + ncclRecv in one group,
+ * one fixed-size message of junction_max_num x 256 floats + the row count each way: 1 MiB at 1024 key points, a few
+ * microseconds on one xGMI link), after which each side matches left against right with ppg_match_nn / ppg_match_mutual.
+ * desc: n rows of 256 floats (host); partner_desc: room for junction_max_num rows (host); *n_partner = rows received.
+ * Both sides call it for every frame, with contexts of the same junction_max_num.  Blocks until the swap is done. */
+int ppg_stereo_swap(ppg_shutter* sh, int partner, const float* desc, int n, float* partner_desc, int* n_partner);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libppgfront.so")
 DEFAULT_WEIGHTS = os.path.join(_HERE, "weights", "ppg_weights.bin")
 HEADER = os.path.join(_HERE, "..", "include", "ppgfront.h")
 
-PPG_OK, PPG_EINVAL, PPG_EHIP, PPG_EIO, PPG_ENOMEM, PPG_ECAP, PPG_ERANGE = 0, -1, -2, -3, -4, -5, -6
+PPG_OK, PPG_EINVAL, PPG_EHIP, PPG_EIO, PPG_ENOMEM, PPG_ECAP, PPG_ERANGE, PPG_ECOMM = 0, -1, -2, -3, -4, -5, -6, -7
+SHUTTER_ID_BYTES = 128
 T_FEAT, T_JUNC, T_HEAT_RAW, T_DESCMAP, T_SCORE, T_HEAT, T_HEAT_REFINED, T_HEAT_REMAPPED = range(8)
 MATCH_PLAIN, MATCH_INIT = 0, 1
 
@@ -47,6 +48,65 @@ class MapGraph(C.Structure):
 _lib = None
 
 
+def mapped_runtimes():
+    """Paths of the HIP / HSA / RCCL runtime images this process maps, by kind (read from /proc/self/maps)."""
+    out = {"amdhip64": set(), "hsa-runtime64": set(), "rccl": set()}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                base = os.path.basename(path)
+                for kind in out:
+                    if base.startswith("lib" + kind + ".so"):
+                        out[kind].add(path)
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in out.items()}
+
+
+def _torch_bundled(name):
+    """Path of a runtime library that an installed PyTorch-ROCm wheel bundles (torch/lib/<name>), or None."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    p = os.path.join(os.path.dirname(spec.origin), "lib", name)
+    return p if os.path.exists(p) else None
+
+
+def _one_hip_runtime():
+    """Makes sure the process ends up with ONE HIP runtime image, whatever the import order.
+
+    libppgfront.so needs `libamdhip64.so.7` and finds the ROCm installation's copy through its RUNPATH.  A PyTorch-ROCm
+    wheel bundles its own copy under torch/lib and asks for it by the unversioned name `libamdhip64.so`, which the
+    dynamic loader does not match against an image loaded under the soname: importing torch AFTER this library therefore
+    maps a second HIP runtime and a second HSA runtime beside the first, both opening the GPU (seen as device discovery
+    failing now and then).  The other order is harmless: torch's image carries the soname `libamdhip64.so.7`, so this
+    library binds to it.  Hence: if a HIP runtime is mapped already, nothing to do; else, if an installed torch bundles
+    one, that image is loaded first (torch later finds the same file), unless PPG_HIP_RUNTIME=system asks for the ROCm
+    installation's runtime (then torch must not be imported afterwards; Context() checks)."""
+    if mapped_runtimes()["amdhip64"]:
+        return
+    if os.environ.get("PPG_HIP_RUNTIME", "") == "system":
+        return
+    p = _torch_bundled("libamdhip64.so")
+    if p:
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+def check_single_runtime():
+    """Raises when two HIP (or HSA) runtime images are mapped: a state in which GPU discovery fails intermittently."""
+    m = mapped_runtimes()
+    for kind in ("amdhip64", "hsa-runtime64"):
+        if len(m[kind]) > 1:
+            raise RuntimeError("two %s runtime images are mapped in this process (%s): import torch BEFORE loading libppgfront.so, "
+                               "or let ppg_slam_amd.lib() load the library (it binds to the runtime torch bundles); "
+                               "with PPG_HIP_RUNTIME=system torch must not be imported at all" % (kind, ", ".join(m[kind])))
+
+
 def lib():
     """Load libppgfront.so; raises if it has not been built (there is no fallback)."""
     global _lib
@@ -54,7 +114,21 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C ppg-slam_amd/csrc` "
                                "(__graft_entry__.build()); the front-end has no CPU path")
+        _one_hip_runtime()
         L = C.CDLL(LIB_PATH)
+        check_single_runtime()
+        L.ppg_create_matcher.restype = C.c_void_p
+        L.ppg_create_matcher.argtypes = [C.POINTER(Config)]
+        L.ppg_set_tunables.argtypes = [C.c_void_p, C.POINTER(Config)]
+        L.ppg_shutter_create.restype = C.c_void_p
+        L.ppg_shutter_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ppg_shutter_destroy.argtypes = [C.c_void_p]
+        L.ppg_shutter_unique_id.argtypes = [C.c_void_p]
+        L.ppg_shutter_release.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.ppg_shutter_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.ppg_shutter_drain.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.ppg_shutter_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+        L.ppg_stereo_swap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.ppg_create.restype = C.c_void_p
         L.ppg_create.argtypes = [C.POINTER(Config)]
         L.ppg_destroy.argtypes = [C.c_void_p]
@@ -125,13 +199,19 @@ def _frame_to_dict(o):
 class Context:
     """Owns one ppg_ctx (one GPU, one stream)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, matcher_only=False):
+        """matcher_only: ppg_create_matcher, a context without networks, frame buffers or warm-up (one per matching thread)."""
         self.cfg = cfg
         self.L = lib()
-        self.h = self.L.ppg_create(C.byref(cfg))
+        check_single_runtime()
+        self.h = (self.L.ppg_create_matcher if matcher_only else self.L.ppg_create)(C.byref(cfg))
         if not self.h:
-            raise PPGError("ppg_create failed: " + self.L.ppg_last_error(None).decode())
+            raise PPGError(("ppg_create_matcher" if matcher_only else "ppg_create") + " failed: " + self.L.ppg_last_error(None).decode())
         self.H, self.W = cfg.height, cfg.width
+
+    def set_tunables(self, cfg):
+        """ppg_set_tunables: the thresholds of cfg apply from the next frame on; returns the status code."""
+        return self.L.ppg_set_tunables(C.c_void_p(self.h), C.byref(cfg))
 
     def close(self):
         if getattr(self, "h", None):

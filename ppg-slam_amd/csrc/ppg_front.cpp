@@ -5,6 +5,7 @@
 // as the reference's -O3 build without FMA code generation does.
 #include "../../include/ppgfront.h"
 #include "ppg_kernels.h"
+#include "ppg_internal.h"
 #include "host_pool.h"
 #include "lines_tail.h"
 #include "vocab.h"
@@ -43,6 +44,16 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 void* g_scratch_ptr[kMaxDevices] = {};
+// Order of the calls that share a GPU's copy of `scratch`: host threads take the device's mutex while they enqueue (a
+// blocking call keeps it until its results are in place); a call on another stream than its predecessor's first makes
+// its stream wait for the event recorded behind that one.
+struct ScratchGuard {
+    std::mutex mu;
+    hipEvent_t done = nullptr;     // recorded behind the last call's kernels
+    hipStream_t last = nullptr;    // the stream they went to
+    bool used = false;
+};
+ScratchGuard g_scratch_guard[kMaxDevices];
 
 struct Tensor {
     std::vector<uint32_t> dims;
@@ -132,6 +143,7 @@ struct ppg_ctx {
     std::string weights_path;
     std::string err;
     int W = 0, H = 0, w8 = 0, h8 = 0, B = 0, maxn = 0;
+    bool matcher_only = false;   // ppg_create_matcher: streams and the matcher's work arrays only
     Lane lane[kLanes];
     int lane_cur = 0, nlanes = 1;  // PPG_CNN_LANES=2 alternates consecutive batches between two CNN streams
     hipStream_t stream = nullptr;       // CNN: image upload and every convolution (alias of the current lane's)
@@ -265,10 +277,17 @@ int scratch_setup(ppg_ctx* c, int dev) {
     if (!g_scratch_ptr[dev]) {
         void* p = nullptr;
         HIPCHK(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        HIPCHK(c, hipEventCreateWithFlags(&g_scratch_guard[dev].done, hipEventDisableTiming));
         g_scratch_ptr[dev] = p;
     }
     return PPG_OK;
 }
+
+// the entry points of the extractor (and those that read resident frames) do not exist on a matcher-only context
+#define NEED_EXTRACTOR(c, what)                                                                                  \
+    do {                                                                                                         \
+        if ((c)->matcher_only) return fail((c), PPG_EINVAL, "%s: this context was made by ppg_create_matcher and has no extractor", what); \
+    } while (0)
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -767,6 +786,19 @@ float* tensor_ptr(ppg_ctx* c, int which) {
 
 }  // namespace
 
+int ppg_set_error(ppg_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_err = buf;
+    return code;
+}
+int ppg_ctx_device(const ppg_ctx* c) { return c->cfg.device_id; }
+int ppg_ctx_max_num(const ppg_ctx* c) { return c->maxn; }
+
 extern "C" {
 
 void ppg_default_config(ppg_config* c, int width, int height) {
@@ -833,13 +865,18 @@ static int create_impl(ppg_ctx* c) {
     if (f.junction_nms_radius != 4) return fail(c, PPG_EINVAL, "only JUNCTION_NMS_RADIUS = 4 is built");
     if (f.desc_dim != 256) return fail(c, PPG_EINVAL, "only DESC_DIM_SIZE = 256 is built");
     if (f.junction_max_num < 1 || f.junction_max_num > 4096) return fail(c, PPG_EINVAL, "junction_max_num must be 1..4096");
-    if (f.max_batch < 1 || f.max_batch > 64) return fail(c, PPG_EINVAL, "max_batch must be 1..64");
-    if (f.heatmap_refine_sz < 1 || f.heatmap_refine_sz > 16) return fail(c, PPG_EINVAL, "heatmap_refine_sz must be 1..16");
-    if (f.precision < 0 || f.precision > 3) return fail(c, PPG_EINVAL, "precision %d is not built", f.precision);
-    if (!f.weights_path) return fail(c, PPG_EINVAL, "weights_path is NULL");
-    c->weights_path = f.weights_path;
-    c->cfg.weights_path = c->weights_path.c_str();
-    c->W = f.width; c->H = f.height; c->w8 = c->W / 8; c->h8 = c->H / 8; c->B = f.max_batch; c->maxn = (int)f.junction_max_num;
+    if (c->matcher_only) {
+        c->cfg.weights_path = nullptr;
+        c->cfg.max_batch = 0;
+    } else {
+        if (f.max_batch < 1 || f.max_batch > 64) return fail(c, PPG_EINVAL, "max_batch must be 1..64");
+        if (f.heatmap_refine_sz < 1 || f.heatmap_refine_sz > 16) return fail(c, PPG_EINVAL, "heatmap_refine_sz must be 1..16");
+        if (f.precision < 0 || f.precision > 3) return fail(c, PPG_EINVAL, "precision %d is not built", f.precision);
+        if (!f.weights_path) return fail(c, PPG_EINVAL, "weights_path is NULL");
+        c->weights_path = f.weights_path;
+        c->cfg.weights_path = c->weights_path.c_str();
+    }
+    c->W = f.width; c->H = f.height; c->w8 = c->W / 8; c->h8 = c->H / 8; c->B = c->cfg.max_batch; c->maxn = (int)f.junction_max_num;
     int ndev = 0;
     HIPCHK(c, hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(c, PPG_EHIP, "no HIP device: libppgfront has no CPU path");
@@ -891,11 +928,17 @@ static int create_impl(ppg_ctx* c) {
         int t = e ? atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / (unsigned)ranks));
         c->host_threads = std::max(1, std::min(t, 64));
     }
-    int rc = load_weights(c);
-    if (rc) return rc;
-    const size_t B = c->B, HW = (size_t)c->H * c->W, hw = (size_t)c->h8 * c->w8;
+    int rc = PPG_OK;
 #define DA(ptr, n) do { rc = dalloc(c, &c->ptr, (n)); if (rc) return rc; } while (0)
 #define HA(ptr, n) do { rc = halloc(c, &c->ptr, (n)); if (rc) return rc; } while (0)
+    if (c->matcher_only) {   // the streams above, the match counter, and work arrays that grow with the first calls
+        DA(mCount, 16);
+        HA(h_mcount, 4);
+        return PPG_OK;
+    }
+    rc = load_weights(c);
+    if (rc) return rc;
+    const size_t B = c->B, HW = (size_t)c->H * c->W, hw = (size_t)c->h8 * c->w8;
     for (int li = 0; li < c->nlanes; li++) {
         Lane& l = c->lane[li];
 #define DL(ptr, n) do { rc = dalloc(c, &l.ptr, (n)); if (rc) return rc; } while (0)
@@ -1020,11 +1063,12 @@ static int create_impl(ppg_ctx* c) {
     return ppg_extract_batch(c, wp.data(), (int)B, c->W, tmp.data());
 }
 
-ppg_ctx* ppg_create(const ppg_config* cfg) {
+static ppg_ctx* create_common(const ppg_config* cfg, bool matcher_only) {
     if (!cfg) { fail(nullptr, PPG_EINVAL, "cfg is NULL"); return nullptr; }
     ppg_ctx* c = new (std::nothrow) ppg_ctx();
     if (!c) { fail(nullptr, PPG_ENOMEM, "out of host memory"); return nullptr; }
     c->cfg = *cfg;
+    c->matcher_only = matcher_only;
     const int rc = create_impl(c);
     if (rc != PPG_OK) {
         g_err = c->err;
@@ -1034,12 +1078,35 @@ ppg_ctx* ppg_create(const ppg_config* cfg) {
     return c;
 }
 
+ppg_ctx* ppg_create(const ppg_config* cfg) { return create_common(cfg, false); }
+
+ppg_ctx* ppg_create_matcher(const ppg_config* cfg) { return create_common(cfg, true); }
+
+int ppg_set_tunables(ppg_ctx* c, const ppg_config* f) {
+    if (!c) return PPG_EINVAL;
+    if (!f) return fail(c, PPG_EINVAL, "ppg_set_tunables: cfg is NULL");
+    NEED_EXTRACTOR(c, "ppg_set_tunables");
+    if (any_inflight(c)) return fail(c, PPG_EINVAL, "ppg_set_tunables: a submitted batch is pending: call ppg_wait_batch first");
+    if (f->desc_dim != c->cfg.desc_dim || f->junction_nms_radius != c->cfg.junction_nms_radius || f->junction_max_num != c->cfg.junction_max_num)
+        return fail(c, PPG_ECAP, "ppg_set_tunables: desc_dim, junction_nms_radius and junction_max_num size buffers and kernels: create a new context");
+    if (f->heatmap_refine_sz < 1 || f->heatmap_refine_sz > 16) return fail(c, PPG_EINVAL, "heatmap_refine_sz must be 1..16");
+    c->cfg.junction_thresh = f->junction_thresh;
+    c->cfg.line_valid_thresh = f->line_valid_thresh;
+    c->cfg.line_valid_ratio = f->line_valid_ratio;
+    c->cfg.line_dist_thresh = f->line_dist_thresh;
+    c->cfg.heatmap_refine_sz = f->heatmap_refine_sz;
+    c->cfg.line_heatmap_thresh = f->line_heatmap_thresh;
+    c->cfg.line_inlier_rate = f->line_inlier_rate;
+    return PPG_OK;
+}
+
 void* ppg_stream(ppg_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 size_t ppg_tensor_elems(const ppg_ctx* c, int which) { return c ? tensor_elems(c, which) : 0; }
 
 int ppg_read_tensor(ppg_ctx* c, int which, int frame, float* dst, size_t n) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_read_tensor");
     const size_t e = tensor_elems(c, which);
     if (!e || !dst || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_read_tensor: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -1051,6 +1118,7 @@ int ppg_read_tensor(ppg_ctx* c, int which, int frame, float* dst, size_t n) {
 
 int ppg_write_tensor(ppg_ctx* c, int which, int frame, const float* src, size_t n) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_write_tensor");
     const size_t e = tensor_elems(c, which);
     if (!e || !src || n != e || frame < 0 || frame >= c->B) return fail(c, PPG_EINVAL, "ppg_write_tensor: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -1068,6 +1136,7 @@ bool early_post(const ppg_ctx* c, int n);
 
 int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_inference");
     if (!imgs || n < 1 || n > c->B) return fail(c, PPG_EINVAL, "ppg_inference: n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const size_t HW = (size_t)c->H * c->W;
@@ -1147,6 +1216,7 @@ bool early_post(const ppg_ctx* c, int n) {
 
 int ppg_detect_keypoints(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "this stage");
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     // the slot's counters are cleared before the stream waits for the networks: the clear then runs beside them instead
@@ -1162,6 +1232,7 @@ int ppg_detect_keypoints(ppg_ctx* c, int n) {
 
 int ppg_detect_lines(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "this stage");
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamWaitEvent(c->post, early_post(c, n) ? c->slot[c->cur].heat_done : c->slot[c->cur].cnn_done, 0));
@@ -1200,6 +1271,7 @@ int ppg_detect_lines(ppg_ctx* c, int n) {
 
 int ppg_gen_descriptors(ppg_ctx* c, int n) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "this stage");
     if (n < 1 || n > c->B) return fail(c, PPG_EINVAL, "n = %d outside 1..%d", n, c->B);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamWaitEvent(c->post, c->slot[c->cur].cnn_done, 0));
@@ -1356,6 +1428,7 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
 
 int ppg_collect(ppg_ctx* c, int n, ppg_frame_out* outs) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_collect");
     if (n < 1 || n > c->B || !outs) return fail(c, PPG_EINVAL, "ppg_collect: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     int rc = enqueue_d2h(c, c->cur, n);
@@ -1406,12 +1479,14 @@ static int submit_common(ppg_ctx* c, const uint8_t* imgs, int n, int on_device, 
 
 int ppg_submit_batch_device(ppg_ctx* c, const uint8_t* d_imgs, int n, int match_prev, float nnratio) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_submit_batch_device");
     if (!d_imgs || n < 1 || n > c->B) return fail(c, PPG_EINVAL, "ppg_submit_batch_device: bad argument");
     return submit_common(c, d_imgs, n, 1, match_prev, nnratio);
 }
 
 int ppg_submit_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, int match_prev, float nnratio) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_submit_batch");
     const uint8_t* staged = nullptr;
     int rc = stage_host_images(c, imgs, n, row_stride, &staged);
     if (rc) return rc;
@@ -1420,6 +1495,7 @@ int ppg_submit_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stri
 
 int ppg_wait_batch(ppg_ctx* c, ppg_frame_out* outs, int32_t* m12, int* n_matches) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_wait_batch");
     if (!outs) return fail(c, PPG_EINVAL, "ppg_wait_batch: outs is NULL");
     // slots alternate, so the older pending batch is the one that is not current (if it is pending)
     int si = c->cur;
@@ -1479,6 +1555,7 @@ static int stage_host_images(ppg_ctx* c, const uint8_t* const* imgs, int n, int 
 
 int ppg_extract_batch(ppg_ctx* c, const uint8_t* const* imgs, int n, int row_stride, ppg_frame_out* outs) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_extract_batch");
     if (!outs) return fail(c, PPG_EINVAL, "ppg_extract_batch: outs is NULL");
     if (any_inflight(c))
         return fail(c, PPG_EINVAL, "a submitted batch is pending: call ppg_wait_batch first");
@@ -1494,6 +1571,7 @@ int ppg_extract(ppg_ctx* c, const uint8_t* img, int row_stride, ppg_frame_out* o
 
 int ppg_extract_batch_device(ppg_ctx* c, const uint8_t* d_imgs, int n, ppg_frame_out* outs) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_extract_batch_device");
     if (!d_imgs || !outs || n < 1 || n > c->B) return fail(c, PPG_EINVAL, "ppg_extract_batch_device: bad argument");
     return extract_common(c, d_imgs, n, 1, outs);
 }
@@ -1647,6 +1725,13 @@ int ppg_match_nn_noalloc(ppg_ctx* c, const float* dA, int nA, const float* dB, i
     float* work = (float*)g_scratch_ptr[c->cfg.device_id];  // this GPU's copy, looked up at ppg_create
     if (!work) return fail(c, PPG_EHIP, "ppg_match_nn_noalloc: the work memory of device %d was never set up", c->cfg.device_id);
     hipStream_t s = stream ? (hipStream_t)stream : c->post;
+    // One call at a time per GPU on the host, and device-side order between calls on different streams (see ScratchGuard).
+    ScratchGuard& guard = g_scratch_guard[c->cfg.device_id];
+    std::lock_guard<std::mutex> lk(guard.mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) HIPCHK(c, hipStreamIsCapturing(s, &cap));
+    const bool capturing = cap != hipStreamCaptureStatusNone;   // a captured call cannot wait for, or be waited for by, an event outside its graph
+    if (!capturing && guard.used && guard.last != s) HIPCHK(c, hipStreamWaitEvent(s, guard.done, 0));
     if (nA > 0) {
         // Nothing in the work memory has to start at zero: the kernels below write every distance and list entry of
         // the nA x nB problem before they read it, and never read beyond it.
@@ -1664,7 +1749,12 @@ int ppg_match_nn_noalloc(ppg_ctx* c, const float* dA, int nA, const float* dB, i
     } else if (mode == PPG_MATCH_INIT) {
         HIPCHK(c, hipMemsetAsync(d_n_matches, 0, sizeof(int), s));
     }
-    if (!stream) HIPCHK(c, hipStreamSynchronize(s));
+    if (!capturing) {
+        HIPCHK(c, hipEventRecord(guard.done, s));
+        guard.last = s;
+        guard.used = true;
+    }
+    if (!stream) HIPCHK(c, hipStreamSynchronize(s));   // (still under the lock: the work memory is free when the next caller gets it)
     return PPG_OK;
 }
 
@@ -2079,6 +2169,7 @@ static int match_resident(ppg_ctx* c, const float* dA, const int* nA, const floa
 
 int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, int* n_matches) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_match_frames");
     Slot& sl = c->slot[c->cur];
     if (any_inflight(c)) return fail(c, PPG_EINVAL, "a submitted batch is pending");
     if (fa < 0 || fb < 0 || fa >= sl.n || fb >= sl.n || !m12)
@@ -2099,6 +2190,7 @@ int ppg_match_frames(ppg_ctx* c, int fa, int fb, float nnratio, int32_t* m12, in
 
 int ppg_match_prev_batch(ppg_ctx* c, int n, float nnratio, int32_t* m12, int* n_matches) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_match_prev_batch");
     Slot& sl = c->slot[c->cur];
     const Slot& prev = c->slot[prev_slot(c->cur)];
     if (any_inflight(c)) return fail(c, PPG_EINVAL, "a submitted batch is pending");
@@ -2481,6 +2573,7 @@ int ppg_bow_transform(ppg_ctx* c, const ppg_vocab* v, const float* desc, int n, 
 int ppg_bow_transform_batch(ppg_ctx* c, const ppg_vocab* v, int n_frames, int levelsup, int32_t* word_id, double* weight,
                             int32_t* node_id) {
     if (!c) return PPG_EINVAL;
+    NEED_EXTRACTOR(c, "ppg_bow_transform_batch");
     const Slot& sl = c->slot[c->cur];
     if (any_inflight(c)) return fail(c, PPG_EINVAL, "a submitted batch is pending");
     if (!v || v->dim != 256 || n_frames < 1 || n_frames > sl.n || !word_id || !weight || !node_id)

@@ -75,15 +75,15 @@ struct FeatureVectorView {
     }
 };
 
-// feature/src/MapPoint.cpp:22-29.  One pair per call launches a 1x1 distance matrix on the GPU; batch
-// pairs with ppg_dist_matrix wherever the caller has more than one.
-inline float DescriptorDistance(ppg_ctx* ctx, const DescMat& a, const DescMat& b) {
+// feature/src/MapPoint.cpp:22-29 (also called in a loop from MapPoint.cpp:277).  Host arithmetic only: the same
+// fused-multiply-add chain as every kernel of the library, bit for bit, with no launch, no context and no effect on
+// batches in flight.  Callers with many pairs batch them with ppg_dist_matrix / ppg_dist_lists.
+inline float DescriptorDistance(const DescMat& a, const DescMat& b) {
     if (a.cols != b.cols) throw std::invalid_argument("DescriptorDistance: column mismatch");
-    float d = 0.f;
-    if (ppg_dist_matrix(ctx, a.data.data(), 1, b.data.data(), 1, a.cols, &d) != PPG_OK)
-        throw std::runtime_error(std::string("libppgfront: ") + ppg_last_error(ctx));
-    return d;
+    return ppg_descriptor_distance(a.data.data(), b.data.data(), a.cols);
 }
+// (the context is not needed; kept so that code written against the earlier signature still compiles)
+inline float DescriptorDistance(ppg_ctx*, const DescMat& a, const DescMat& b) { return DescriptorDistance(a, b); }
 
 class Matcher {
 public:

@@ -28,7 +28,7 @@ public:
              std::vector<KeyEdge>& _keyedges, DescMat& _descriptors) {
         if (srcMat.channels() != 1 || srcMat.rows != mCam.height || srcMat.cols != mCam.width)
             throw std::invalid_argument("PPGExtractor::run: image must be single-channel and match the camera size");
-        if (tunables_changed()) rebuild();
+        apply_tunables();
         ppg_frame_out o;
         check(ppg_extract(mCtx, srcMat.data, srcMat.step, &o));
         absorb(o);
@@ -44,7 +44,7 @@ public:
 
     // The four public pipeline stages (feature/include/PPGExtractor.h:56-65)
     void inference(GrayImage undistortedMat) {
-        if (tunables_changed()) rebuild();
+        apply_tunables();
         std::vector<uint8_t> tight((size_t)mCam.width * mCam.height);
         for (int y = 0; y < mCam.height; y++)
             std::memcpy(tight.data() + (size_t)y * mCam.width, undistortedMat.data + (size_t)y * undistortedMat.step, mCam.width);
@@ -104,8 +104,20 @@ private:
                c.line_dist_thresh != mCfg.line_dist_thresh || c.heatmap_refine_sz != mCfg.heatmap_refine_sz ||
                c.line_heatmap_thresh != mCfg.line_heatmap_thresh || c.line_inlier_rate != mCfg.line_inlier_rate;
     }
-    // The reference's tunables are mutable statics read on every frame; the context fixes them at creation,
-    // so a change re-creates it (constructor semantics, incl. warm-up, PPGExtractor.cpp:55-107).
+    // The reference's tunables are mutable statics read on every frame (feature/include/PPGExtractor.h:105-114).  The
+    // thresholds are handed to the context as they are (ppg_set_tunables: no buffer, weight or warm-up is touched); only
+    // the three that size buffers and kernels (DESC_DIM_SIZE, JUNCTION_NMS_RADIUS, JUNCTION_MAX_NUM) re-create it.
+    void apply_tunables() {
+        if (!tunables_changed()) return;
+        ppg_config c = mCfg;
+        fill_cfg(c);
+        c.weights_path = mCfg.weights_path;
+        c.max_batch = mCfg.max_batch;
+        const int rc = ppg_set_tunables(mCtx, &c);
+        if (rc == PPG_OK) { mCfg = c; return; }
+        if (rc != PPG_ECAP) check(rc);
+        rebuild();
+    }
     void rebuild() {
         if (mCtx) ppg_destroy(mCtx);
         mWeights = mDataPath + "/ppg_weights.bin";

@@ -2,6 +2,7 @@
 // map/src/Frame.cpp:62 and system/src/Tracking.cpp:524-525 use the reference classes.
 // Usage: shim_demo <weights dir> <raw u8 image A> <raw u8 image B> <width> <height> [projection dump file]
 // Prints one line of integers that tests/test_gpu_parity.py compares with the C-ABI results.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -190,6 +191,25 @@ int main(int argc, char** argv) {
         for (auto& kp : F[0].mvKeysUn) prev.emplace_back(kp.mPos[0], kp.mPos[1]);
         std::vector<int> m12;
         const int nm = matcher.SearchForInitialization(F[0], F[1], prev, m12, 50);
+        {   // the free function DescriptorDistance (host arithmetic, no context) against the GPU's distance matrix, bit for bit
+            const int na = std::min<int>(16, (int)F[0].mvKeysUn.size()), nb = std::min<int>(16, (int)F[1].mvKeysUn.size());
+            std::vector<float> D((size_t)na * nb);
+            if (na && nb && ppg_dist_matrix(ext.context(), F[0].mDescriptors.ptr(0), na, F[1].mDescriptors.ptr(0), nb, 256, D.data()) != PPG_OK) {
+                fprintf(stderr, "ppg_dist_matrix: %s\n", ppg_last_error(ext.context()));
+                return 3;
+            }
+            for (int i = 0; i < na; i++)
+                for (int j = 0; j < nb; j++) {
+                    DescMat a(1, 256), b(1, 256);
+                    std::memcpy(a.ptr(0), F[0].mDescriptors.ptr(i), sizeof(float) * 256);
+                    std::memcpy(b.ptr(0), F[1].mDescriptors.ptr(j), sizeof(float) * 256);
+                    const float d = DescriptorDistance(a, b);
+                    if (std::memcmp(&d, &D[(size_t)i * nb + j], 4) != 0) {
+                        fprintf(stderr, "DescriptorDistance(%d, %d) = %.9g on the host, %.9g on the GPU\n", i, j, d, D[(size_t)i * nb + j]);
+                        return 3;
+                    }
+                }
+        }
         long long chk = 0;
         for (size_t i = 0; i < m12.size(); i++) chk = chk * 31 + (m12[i] + 2);
         size_t conn = 0;

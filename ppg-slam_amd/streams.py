@@ -11,8 +11,124 @@ A stereo rig whose two cameras sit on two GPUs (ranks 2p and 2p+1) may also exch
 descriptors point to point (StereoExchange: one send and one receive of at most max_num x 256 floats
 = 1 MiB, a few microseconds over one xGMI link) so that each side can match left against right with
 the library's matcher.
+
+Two implementations of the barrier with one interface (release / drain / count / pending / released):
+`Shutter` binds the library's own entry points (ppg_shutter_*: RCCL called directly from C, the path a C++ host uses
+and the one bench.py runs on GPUs); `ShutterBarrier` is the same protocol over torch.distributed, which the CPU tests
+drive with the gloo backend and bench.py falls back to when the C entry points cannot be set up.
 """
-import torch
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+try:
+    import torch
+except ImportError:   # the C-ABI binding below does not need it
+    torch = None
+
+
+def _pkg():
+    return sys.modules["ppg_slam_amd"]
+
+
+def _one_rccl_image():
+    """The library looks RCCL up at run time and prefers an image that is already mapped.  When the process runs on
+    the HIP runtime that a PyTorch wheel bundles, the RCCL built against it is the wheel's too: map that one first."""
+    pkg = _pkg()
+    m = pkg.mapped_runtimes()
+    if m["rccl"]:
+        return
+    bundled_hip = pkg._torch_bundled("libamdhip64.so")
+    if bundled_hip and bundled_hip in m["amdhip64"]:
+        p = pkg._torch_bundled("librccl.so")
+        if p:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+def shutter_unique_id():
+    """ppg_shutter_unique_id: 128 bytes that rank 0 makes and hands to every rank."""
+    L = _pkg().lib()
+    _one_rccl_image()
+    buf = (C.c_uint8 * _pkg().SHUTTER_ID_BYTES)()
+    rc = L.ppg_shutter_unique_id(buf)
+    if rc != 0:
+        raise _pkg().PPGError("ppg_shutter_unique_id failed: " + L.ppg_last_error(None).decode())
+    return bytes(buf)
+
+
+class Shutter:
+    """ppg_shutter_*: the global-shutter barrier behind the C ABI (RCCL all-reduce(MIN) on a stream of the library's own,
+    result in pinned memory behind an event).  Same interface as ShutterBarrier."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        self.L = _pkg().lib()
+        _one_rccl_image()
+        self.ctx = ctx
+        self.rank, self.world = rank, world
+        idbuf = (C.c_uint8 * len(unique_id)).from_buffer_copy(unique_id)
+        self.h = self.L.ppg_shutter_create(C.c_void_p(ctx.h), rank, world, idbuf)
+        if not self.h:
+            raise _pkg().PPGError("ppg_shutter_create failed: " + self.L.ppg_last_error(None).decode())
+        self.active = True
+        self.released = -1
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise _pkg().PPGError(f"libppgfront error {rc}: " + self.ctx.last_error())
+
+    def release(self, group: int) -> int:
+        r = C.c_int(-1)
+        self._chk(self.L.ppg_shutter_release(C.c_void_p(self.h), int(group), C.byref(r)))
+        self.released = r.value
+        return r.value
+
+    def poll(self) -> int:
+        r = C.c_int(-1)
+        self._chk(self.L.ppg_shutter_poll(C.c_void_p(self.h), C.byref(r)))
+        self.released = r.value
+        return r.value
+
+    def drain(self) -> int:
+        r = C.c_int(-1)
+        self._chk(self.L.ppg_shutter_drain(C.c_void_p(self.h), C.byref(r)))
+        self.released = r.value
+        return r.value
+
+    def _stats(self):
+        a, b = C.c_longlong(0), C.c_int(0)
+        self._chk(self.L.ppg_shutter_stats(C.c_void_p(self.h), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @property
+    def count(self):
+        return self._stats()[0]
+
+    @property
+    def pending(self):
+        return [None] * self._stats()[1]
+
+    def stereo_swap(self, partner, desc):
+        """ppg_stereo_swap: returns the partner's descriptors [m, 256]."""
+        desc = np.ascontiguousarray(desc, np.float32).reshape(-1, 256)
+        M = int(self.ctx.cfg.junction_max_num)
+        out = np.empty((M, 256), np.float32)
+        m = C.c_int(0)
+        self._chk(self.L.ppg_stereo_swap(C.c_void_p(self.h), int(partner), desc.ctypes.data_as(C.c_void_p), desc.shape[0],
+                                         out.ctypes.data_as(C.c_void_p), C.byref(m)))
+        return out[:m.value].copy()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ppg_shutter_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_streams(n_streams: int, world: int, rank: int):

@@ -371,10 +371,12 @@ def test_reduced_precision_statements_against_the_reference_nets(onet):
 
 
 def test_line_graph_sensitivity_to_libm_reading(orc, onet, synth, capsys):
-    """detectLines calls atan2, abs and sin without saying which overload (feature/src/PPGExtractor.cpp:283, :325, :330,
-    :413).  The oracle can read them three ways (ppgo_cfg.math_mode); this measures, on the golden images and two full-size
-    synthetic frames, whether any edge decision depends on the choice between the float libm functions (mode 0) and the
-    double functions rounded to float (mode 1, the statement the GPU tail implements): none may.  Mode 2 (integer abs, a
+    """detectLines evaluates atan2, abs and sin on floats (feature/src/PPGExtractor.cpp:283, :325, :330, :413).  The literal
+    reading is the float overloads of the host's libm (ppgo_cfg.math_mode 0: :283 and :413 are qualified std:: calls, the
+    unqualified ones resolve to the float overloads under libstdc++'s C wrappers); oracle, library and GPU tail default to
+    a chosen definition instead, the double functions rounded to float (mode 1), which does not depend on the libm.  This
+    measures, on the golden images and on full-size frames of the benchmark's dense streams, that no output of the line
+    graph - edges, scores, per-point adjacency, collinear pairs - differs between the two.  Mode 2 (integer abs, a
     different algorithm) is reported only."""
     from conftest import golden
     cases = []
@@ -382,10 +384,12 @@ def test_line_graph_sensitivity_to_libm_reading(orc, onet, synth, capsys):
         g = golden(name)
         H, W = g["img"].shape
         cases.append((name, W, H, 500, g["refined"], g["kp_un"], g["kp_out"]))
-    for (seed, kind, maxn) in ((11, "dense", 1024), (1, "sparse", 500)):
+    # seeds 1000 * s + 11 are the scenes of bench.py's camera streams s; t is the frame of the stream
+    for (seed, kind, maxn, t) in ((11, "dense", 1024, 0), (1, "sparse", 500, 0), (3011, "dense", 1024, 5), (17011, "dense", 1024, 2),
+                                  (31011, "dense", 1024, 7)):
         H, W = 480, 640
         cfg = orc.default_cfg(W, H, maxn)
-        t = onet.inference(synth.make_frame(H, W, seed, 0, kind))
+        t = onet.inference(synth.make_frame(H, W, seed, t, kind))
         kp = orc.detect_keypoints(cfg, orc.score_map(t["junc"]))
         cases.append((f"{kind}{seed}", W, H, maxn, orc.refine_heat(cfg, orc.heat_prob(t["heat"])), kp["un"], kp["out"]))
     report = []

@@ -121,3 +121,59 @@ def test_noalloc_match_equals_allocating_entry_point(pkg):
     finally:
         hip.free_all()
         ctx.close()
+
+
+def test_noalloc_calls_from_two_contexts_and_threads_do_not_corrupt_each_other(pkg):
+    """Every call on a GPU shares one work array.  Two contexts on two host threads, each enqueueing on a stream of its
+    own, used to race on it; the library now orders them (a per-GPU lock on the host, an event between streams)."""
+    import threading
+    ctxs = [pkg.Context(pkg.default_config(128, 96), matcher_only=True) for _ in range(2)]
+    hip = _Hip()
+    try:
+        rng = np.random.default_rng(99)
+        jobs = []
+        for k, (nA, nB) in enumerate(((1024, 1024), (640, 900))):
+            A, B = _pair(rng, nA, nB)
+            ref = ctxs[k].match_nn(A, B, th=0.7, ratio=0.9, mode=pkg.MATCH_INIT)
+            bufs = dict(dA=hip.to_device(A), dB=hip.to_device(B), dm=hip.to_device(np.zeros(nA, np.int32)),
+                        db=hip.to_device(np.zeros(nA, np.float32)), ds=hip.to_device(np.zeros(nA, np.float32)),
+                        dc=hip.to_device(np.zeros(1, np.int32)), st=hip.stream())
+            jobs.append((nA, nB, ref, bufs))
+        hip.sync()
+        errors = []
+        start = threading.Barrier(2)
+
+        def worker(k):
+            nA, nB, ref, b = jobs[k]
+            try:
+                start.wait()
+                for rep in range(25):
+                    rc = ctxs[k].match_nn_noalloc(b["dA"].value, nA, b["dB"].value, nB, b["dm"].value, b["db"].value,
+                                                  b["ds"].value, b["dc"].value, th=0.7, ratio=0.9, mode=pkg.MATCH_INIT,
+                                                  stream=b["st"].value if rep % 5 else None)   # every fifth call blocks on the context's own stream
+                    if rc != 0:
+                        errors.append((k, rep, ctxs[k].last_error()))
+                        return
+                    assert hip.rt.hipStreamSynchronize(b["st"]) == 0
+                    m = hip.to_host(b["dm"], nA, np.int32)
+                    bd = hip.to_host(b["db"], nA, np.float32)
+                    cnt = int(hip.to_host(b["dc"], 1, np.int32)[0])
+                    if not (np.array_equal(m, ref[0]) and np.array_equal(bd, ref[1]) and cnt == ref[3]):
+                        errors.append((k, rep, "result differs from ppg_match_nn"))
+            except Exception as e:  # noqa: BLE001
+                errors.append((k, repr(e)))
+
+        hip.rt.hipStreamSynchronize.argtypes = [hip.C.c_void_p]
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=100)
+            assert not t.is_alive()
+        assert not errors, errors[:4]
+        for _, _, _, b in jobs:
+            hip.rt.hipStreamDestroy(b["st"])
+    finally:
+        hip.free_all()
+        for c in ctxs:
+            c.close()
