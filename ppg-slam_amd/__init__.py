@@ -98,9 +98,11 @@ def _one_hip_runtime():
 
 
 def check_single_runtime():
-    """Raises when two HIP (or HSA) runtime images are mapped: a state in which GPU discovery fails intermittently."""
+    """Raises when two HIP runtime images are mapped: a state in which GPU discovery fails intermittently.  (Two HSA images
+    alone are what a process under rocprofv3 looks like - the profiler's tool library maps the ROCm installation's copy
+    before the program starts - and are not refused.)"""
     m = mapped_runtimes()
-    for kind in ("amdhip64", "hsa-runtime64"):
+    for kind in ("amdhip64",):
         if len(m[kind]) > 1:
             raise RuntimeError("two %s runtime images are mapped in this process (%s): import torch BEFORE loading libppgfront.so, "
                                "or let ppg_slam_amd.lib() load the library (it binds to the runtime torch bundles); "

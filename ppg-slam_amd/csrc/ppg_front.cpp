@@ -243,6 +243,8 @@ struct ppg_ctx {
     int persist_fused = 0, persist_other = 0;
     int xcd_group = 4, xcd_band = 1;   // XCD-aware launch order of the convolutions (ppg::ConvArgs::xcd_group); PPG_XCD_MAP=0 switches it off
     bool persist_forced = false;  // set by PPG_CONV_PERSIST: the numbers apply to every launch, whatever its size
+    bool conv_ws = true;        // PPG_CONV_WS=0: the reduced-precision layers on the one-tile-per-work-group kernel only (the statement the wave-specialised one is checked against)
+    long conv_ws_min_units = 1024;   // (tile, cout block) units a launch needs before it runs wave-specialised (PPG_CONV_WS_MIN)
     bool no_quarter = false;    // PPG_NO_QUARTER_TILES=1: big convolution tiles whatever the batch size (read at ppg_create)
     bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
     int* mCount = nullptr;
@@ -686,6 +688,13 @@ void conv_tiling(const ppg_ctx* c, ppg::ConvArgs& a, const DevConv& dc, int mode
     if (!c->persist_forced && (long)a.tiles_x * a.tiles_y * a.B < 20L * a.persist) a.persist = 0;
     a.tile_counter = c->lane[c->lane_cur].tile_ctr;
     a.xcd_group = c->xcd_group; a.xcd_band = c->xcd_band;
+    // Reduced-precision 3x3 layers of many tiles run wave-specialised: one resident work-group per CU whose producer
+    // waves stage the next chunk while its consumer waves multiply (conv_ws.hip).  Launches too small to give every CU a
+    // few tiles keep the one-tile-per-work-group kernel.
+    a.ws = 0;
+    if (c->conv_ws && a.prec != 0 && dc.ks == 3 && dc.nt == 2 && a.Cin >= 64 && a.Cin % 16 == 0 && a.xcd_group > 0 &&
+        (long)a.tiles_x * a.tiles_y * a.B * a.nblk >= c->conv_ws_min_units)
+        a.ws = 1;
     if (c->no_quarter || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
     if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;
     a.quarter = 1;
@@ -913,6 +922,8 @@ static int create_impl(ppg_ctx* c) {
         if (const char* pe = getenv("PPG_CONV_PERSIST")) c->persist_forced = sscanf(pe, "%d,%d", &c->persist_fused, &c->persist_other) == 2;
         if (const char* xm = getenv("PPG_XCD_MAP")) c->xcd_group = std::max(0, atoi(xm));
         if (const char* xb = getenv("PPG_XCD_BAND")) c->xcd_band = atoi(xb) != 0;
+        if (const char* w = getenv("PPG_CONV_WS")) c->conv_ws = atoi(w) != 0;
+        if (const char* w = getenv("PPG_CONV_WS_MIN")) c->conv_ws_min_units = std::max(8L, atol(w));
         const char* nq = getenv("PPG_NO_QUARTER_TILES");
         c->no_quarter = nq && atoi(nq) != 0;
         const char* eh = getenv("PPG_EXTEND_HOST");

@@ -45,6 +45,7 @@ struct ConvArgs {
     int xcd_group = 0;
     int xcd_band = 1;
     int xcd_tiles8 = 0;  // set by the launch function: ceil(tiles / 8)
+    int ws = 0;          // 1: the wave-specialised kernel (conv_ws.hip; reduced-precision 3x3 layers with 64-cout blocks, Cin >= 64)
     int quarter = 0;     // 1: quarter-size work-groups (fp32 3x3, 64-cout blocks): 4 x 32 (mw 32) or 8 x 16 (mw 16) pixels x 32 couts
     int ngroups = 1;
     ConvGroup g[3];
@@ -52,6 +53,9 @@ struct ConvArgs {
 
 // ks: 1 or 3; nt: 32-wide cout tiles per wave (1 or 2)
 hipError_t launch_conv(const ConvArgs& a, int ks, int nt, hipStream_t s);
+// the wave-specialised form of a reduced-precision 3x3 launch (a.prec != 0, 64-cout blocks, Cin a multiple of 16 and >= 64);
+// a.tile_counter must point at kTileCounters zeroed ints
+hipError_t launch_conv_ws(const ConvArgs& a, hipStream_t s);
 // cin chunk depth the kernel for (ks) streams through LDS; packers must use the same value
 int conv_chunk(int ks);
 

@@ -5,6 +5,8 @@
 // (keypoints, line candidates, match indices) agree bit for bit with a strict-IEEE CPU evaluation of
 // the reference's formulas.
 #include "ppg_kernels.h"
+#include "conv_split.h"
+#include "conv_store.h"
 
 #include <math.h>
 #include <algorithm>
@@ -12,119 +14,6 @@
 
 namespace ppg {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load from a 4-byte aligned address
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// Epilogue of the convolution kernels: bias, (batch norm), (ReLU), then plain / pooled / pixel-shuffled store.
-// acc[m][n] is the 32 x 32 result of pixel tile m and cout tile n in the MFMA D layout (lane = pixel l&31,
-// register r = cout (r&3) + 8*(r>>2) + 4*(l>>5)).
-template <int NT, int MW, int MT = 2, bool HALF = false>
-__device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc)[MT][NT], int wave, int li, int lh, int x0,
-                                           int y0, int b, int nb_launch) {
-    constexpr int NB = 32 * NT;
-    auto prow = [&](int m, int i) { return MW == 32 ? MT * wave + m : 2 * MT * wave + 2 * m + (i >> 4); };
-    auto pcol = [&](int i) { return MW == 32 ? i : (i & 15); };
-    // HALF: the launch counts 32-cout halves of the 64-cout blocks the layers are described in
-    const int nb = HALF ? nb_launch >> 1 : nb_launch;
-    // A launch may serve up to three layers that read the same input (cout blocks [nblk0, next nblk0) each).
-    // The lane owns one pixel of each pixel tile and, per cout tile, four runs of four consecutive couts
-    // (registers 4j..4j+3 = couts 8j + 4*(l>>5) + 0..3): one 16-byte store per run.
-    int gi = 0;
-    if (a.ngroups > 1 && nb >= a.g[1].nblk0) gi = 1;
-    if (a.ngroups > 2 && nb >= a.g[2].nblk0) gi = 2;
-    const ConvGroup G = a.g[gi];
-    const int cb = HALF ? (nb - G.nblk0) * 64 + (nb_launch & 1) * 32 : (nb - G.nblk0) * NB;  // first cout of this block inside its layer (packed order)
-    const bool bn = G.alpha != nullptr;
-    const bool vec = (G.Cout & 3) == 0;  // rows of the output are 16-byte aligned
-    const int Cps = G.Cout >> 2;
-    // All bias vectors are fetched before the first store: a store to `out` may alias them as far as the compiler
-    // knows, so loads left inside the loops would each wait out a full memory latency behind the stores before them.
-    // (The bias arrays are padded to whole cout blocks.)
-    f32x4 biasv[NT][4];
-#pragma unroll
-    for (int n = 0; n < NT; n++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) biasv[n][j] = *(const f32x4*)(G.bias + cb + n * 32 + 8 * j + 4 * lh);
-    // one run of four couts: BN = the layer has a batch norm (al, be valid)
-    auto run = [&](auto BN, int n, int j, f32x4 bias, f32x4 al, f32x4 be) {
-        const int co = cb + n * 32 + 8 * j + 4 * lh;  // first of the four couts
-        if (co >= G.Cout) return;
-        if (G.mode == CONV_POOL2) {
-            // pooled layers use the 8 x 32 tile with two pixel tiles per wave (rows 2*wave, 2*wave+1 are the two
-            // tiles) or the 8 x 16 tile with one (the tile is two rows of 16: the row neighbour is lane ^ 16);
-            // the column neighbour is the next lane
-            if (!((MW == 32 && MT == 2) || (MW == 16 && MT == 1))) return;
-            const int y = y0 + 2 * wave, x = x0 + pcol(li);
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float t = MT == 2 ? fmaxf(acc[0][n][4 * j + e], acc[MT - 1][n][4 * j + e])
-                                        : fmaxf(acc[0][n][4 * j + e], __shfl_xor(acc[0][n][4 * j + e], 16));
-                const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));  // lane ^ 1
-                float r = fmaxf(t, o) + bias[e];
-                if (G.relu) r = fmaxf(r, 0.f);
-                v[e] = r;
-            }
-            if ((li & 1) == 0 && (MT == 2 || li < 16) && y + 1 < a.H && x + 1 < a.W) {
-                float* dst = G.out + ((size_t)(b * (a.H / 2) + (y >> 1)) * (a.W / 2) + (x >> 1)) * G.Cout + co;
-                if (vec) *(f32x4*)dst = v;
-                else
-                    for (int e = 0; e < 4; e++)
-                        if (co + e < G.Cout) dst[e] = v[e];
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const int y = y0 + prow(m, li), x = x0 + pcol(li);
-                if (y >= a.H || x >= a.W) continue;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float r = acc[m][n][4 * j + e] + bias[e];
-                    if (BN) r = r * al[e] + be[e];
-                    if (G.relu) r = fmaxf(r, 0.f);
-                    v[e] = r;
-                }
-                float* dst;
-                if (G.mode == CONV_PLAIN) {
-                    dst = G.out + ((size_t)(b * a.H + y) * a.W + x) * G.Cout + co;
-                } else {  // CONV_PS2: packed cout = q*Cps + c, q = 2*dy + dx; Cps is a multiple of 4
-                    const int q = co / Cps, cc = co - q * Cps;
-                    dst = G.out + ((size_t)(b * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1)) * Cps + cc;
-                }
-                if (vec) *(f32x4*)dst = v;
-                else
-                    for (int e = 0; e < 4; e++)
-                        if (co + e < G.Cout) dst[e] = v[e];
-            }
-        }
-    };
-    // No load may follow a store here: the counter a load is waited on counts the stores before it too, so a load
-    // in the middle of the epilogue waits out the full write latency of everything stored so far.  Without a batch norm
-    // there is none; with one (a single layer) its eight vectors per cout tile are fetched ahead of that tile's stores.
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
-    if (!bn) {
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) run(std::false_type{}, n, j, biasv[n][j], one, zero);
-    } else {
-#pragma unroll
-        for (int n = 0; n < NT; n++) {
-            f32x4 al[4], be[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int co = min(cb + n * 32 + 8 * j + 4 * lh, G.Cout - 4);  // (runs past the layer are skipped below)
-                al[j] = *(const f32x4*)(G.alpha + co);
-                be[j] = *(const f32x4*)(G.beta + co);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) run(std::true_type{}, n, j, biasv[n][j], al[j], be[j]);
-        }
-    }
-}
 
 // =====================================================================================
 // Convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32: each product is one fmaf into
@@ -422,39 +311,6 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
 #ifndef PPG_EXP_LDS
 #define PPG_EXP_LDS 0
 #endif
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// The fp16 variant of the split (F16): operands are first scaled by exact powers of two (activations 2^5, weights
-// 2^10 on the host) so that hi and lo stay inside fp16's narrow exponent range, and the accumulators are scaled back
-// by 2^-15 before the bias.  fp16 keeps 11 bits per half instead of 8: the three products carry about 22 significant
-// bits of each operand, which brings the result to within twice the rounding noise of an fp32 evaluation.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr float kF16ActScale = 0x1p5f, kF16AccUnscale = 0x1p-15f;  // weights carry 2^10
-
-__device__ __forceinline__ void split_f16(float x0, float x1, unsigned& hi, unsigned& lo, bool& sat) {
-    // saturate instead of overflowing to infinity, and report it (activations beyond 2047 do not occur in these
-    // networks; NaN compares false and propagates)
-    x0 *= kF16ActScale; x1 *= kF16ActScale;
-    sat |= fabsf(x0) > 65504.f || fabsf(x1) > 65504.f;
-    x0 = fminf(fmaxf(x0, -65504.f), 65504.f);
-    x1 = fminf(fmaxf(x1, -65504.f), 65504.f);
-    const f16x2 h = {(_Float16)x0, (_Float16)x1};  // round to nearest even
-    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-
-// two floats -> their bf16 hi parts and the bf16 of the remainders, each pair packed into one dword
-__device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const f32x2 x = {x0, x1};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-    const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-}
-
 // KS = 1: a 1x1 layer has one tap per chunk, too little work between two barriers, so G chunks of 16 channels are staged
 // and consumed together (G = 2: 45 KiB of LDS).
 template <int NT, bool FUSE1A, int MW, int TERMS, bool F16 = false, int KS = 3, int G = 1>
@@ -689,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvArgs a) {
 int conv_chunk(int ks) { return ks == 3 ? 8 : 16; }
 
 hipError_t launch_conv(const ConvArgs& args, int ks, int nt, hipStream_t s) {
+    if (args.ws) return (ks == 3 && nt == 2) ? launch_conv_ws(args, s) : hipErrorInvalidValue;
     ConvArgs a = args;
     dim3 grid(a.tiles_x * a.tiles_y * a.B, a.nblk), block(256);
     // fp32 kernels: at most `persist` work-groups per cout block, each walking the tiles with that stride

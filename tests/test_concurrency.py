@@ -48,17 +48,17 @@ def test_matcher_context_is_light_and_rejects_the_extractor(pkg, synth):
 def test_set_tunables_applies_without_a_new_context(pkg, synth, orc, onet):
     """The reference reads its public static tunables on every frame (feature/include/PPGExtractor.h:105-114)."""
     img = _frames(synth, 1)[0]
-    cfg = pkg.default_config(W, H, max_num=500)
+    cfg = pkg.default_config(W, H, max_num=2000)
     ctx = pkg.Context(cfg)
     try:
         a = ctx.extract(img)
-        cfg2 = pkg.default_config(W, H, max_num=500)
-        cfg2.junction_thresh = 0.05
+        cfg2 = pkg.default_config(W, H, max_num=2000)
+        cfg2.junction_thresh = 0.15
         cfg2.line_heatmap_thresh = 0.3
         assert ctx.set_tunables(cfg2) == 0
         b = ctx.extract(img)
-        ocfg = orc.default_cfg(W, H, 500)
-        ocfg.junction_thresh = 0.05
+        ocfg = orc.default_cfg(W, H, 2000)
+        ocfg.junction_thresh = 0.15
         ocfg.line_heatmap_thresh = 0.3
         o = orc.extract(onet, ocfg, img)
         assert b["n"] == o["n"] < a["n"] and np.array_equal(b["xy"], o["xy"]) and np.array_equal(b["edge_idx"], o["edge_idx"])

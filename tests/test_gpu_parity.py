@@ -266,6 +266,38 @@ def test_xcd_order_equals_plain_order(pkg, synth, monkeypatch):
                 c.close()
 
 
+def test_wave_specialised_convolutions_equal_plain_ones(pkg, synth, monkeypatch):
+    """The reduced-precision 3x3 layers of large launches run wave-specialised (conv_ws_kernel: one resident work-group per
+    CU, producer waves staging the next chunk for consumer waves, tiles drawn from per-XCD counters that the kernel leaves
+    at zero: every context below extracts twice); PPG_CONV_WS=0 keeps every layer on the one-tile-per-work-group kernel.
+    Same arithmetic in the same order: every network output must be bit-identical, in modes 1, 2 and 3, on sizes whose tile
+    counts do and do not divide evenly, with every layer forced onto the new kernel (PPG_CONV_WS_MIN=8) and with the
+    production threshold."""
+    cases = ((480, 640, 4, 1, "8"), (480, 640, 3, 3, "8"), (120, 136, 5, 1, "8"), (72, 104, 7, 3, "8"), (96, 128, 2, 2, "8"),
+             (480, 640, 5, 1, None), (240, 320, 1, 1, "8"))
+    for (H, W, n, prec, ws_min) in cases:
+        imgs = [synth.make_frame(H, W, 1310 + k, 0, "dense" if k % 2 else "sparse") for k in range(n)]
+        monkeypatch.setenv("PPG_CONV_WS", "0")
+        plain = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500, precision=prec))
+        monkeypatch.setenv("PPG_CONV_WS", "1")
+        if ws_min:
+            monkeypatch.setenv("PPG_CONV_WS_MIN", ws_min)
+        spec = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500, precision=prec))
+        monkeypatch.delenv("PPG_CONV_WS")
+        monkeypatch.delenv("PPG_CONV_WS_MIN", raising=False)
+        try:
+            for rep in range(2):
+                ra, rb = plain.extract_batch(imgs), spec.extract_batch(imgs)
+                for which in (pkg.T_FEAT, pkg.T_JUNC, pkg.T_HEAT_RAW, pkg.T_DESCMAP):
+                    for f in range(n):
+                        assert np.array_equal(plain.read_tensor(which, f), spec.read_tensor(which, f)), (H, W, n, prec, which, f, rep)
+                for x, y in zip(ra, rb):
+                    assert np.array_equal(x["xy"], y["xy"]) and np.array_equal(x["desc"], y["desc"]) and np.array_equal(x["edge_idx"], y["edge_idx"])
+        finally:
+            plain.close()
+            spec.close()
+
+
 def test_tile_walk_equals_one_group_per_tile(pkg, synth, monkeypatch):
     """Large launches of the fused first convolution run a fixed number of work-groups that take their tiles from a counter
     (which the kernel leaves at zero for the next launch: every context below extracts twice);

