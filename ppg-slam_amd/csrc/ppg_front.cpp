@@ -693,7 +693,7 @@ void conv_tiling(const ppg_ctx* c, ppg::ConvArgs& a, const DevConv& dc, int mode
     // few tiles keep the one-tile-per-work-group kernel.
     a.ws = 0;
     if (c->conv_ws && a.prec != 0 && dc.ks == 3 && dc.nt == 2 && a.Cin >= 64 && a.Cin % 16 == 0 && a.xcd_group > 0 &&
-        (long)a.tiles_x * a.tiles_y * a.B * a.nblk >= c->conv_ws_min_units)
+        (long)a.tiles_x * a.tiles_y * a.B * a.nblk >= c->conv_ws_min_units && !(mode == ppg::CONV_POOL2 && a.mw != 32))
         a.ws = 1;
     if (c->no_quarter || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
     if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     const int prec = argc > 3 ? atoi(argv[3]) : 0;
     const int use_ws = argc > 4 ? atoi(argv[4]) : 0;
     int* dctr; hipMalloc(&dctr, 256 * sizeof(int)); hipMemset(dctr, 0, 256 * sizeof(int));
-    unsigned long long* dwst; hipMalloc(&dwst, 64);
+    unsigned long long* dwst; hipMalloc(&dwst, 128);
     hipMemcpyToSymbol(HIP_SYMBOL(ppg::g_ws_timing), &dwst, sizeof(dwst));
     std::vector<L> ls = {
         {"conv1b fused pool", 480, 640, 64, 64, CONV_POOL2, 1, 32, 2},
@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         const int reps = 10;
         hipMemset(dtim, 0, 32);
-        hipMemset(dwst, 0, 64);
+        hipMemset(dwst, 0, 128);
         float est; { hipEventRecord(e0); launch_conv(a, l.ks, l.nt, 0); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&est, e0, e1); }
         hipEventRecord(e0);
         clock_probe<<<1, 64, 0, s2>>>(dclk, (long long)(est * reps * 0.8 * 1e5));
@@ -103,12 +103,12 @@ int main(int argc, char** argv) {
         hipMemcpy(htim, dtim, 32, hipMemcpyDeviceToHost);
         const double nw = htim[3] ? (double)htim[3] : 1.0;
         if (a.ws) {
-            unsigned long long w[8];
-            hipMemcpy(w, dwst, 64, hipMemcpyDeviceToHost);
+            unsigned long long w[16];
+            hipMemcpy(w, dwst, 128, hipMemcpyDeviceToHost);
             const double wg = w[5] ? (double)w[5] : 1.0, mhz = 100.0 * hclk[0] / hclk[1];
-            printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  units=%d  clk=%.0f MHz  WS per work-group: consumer %.1f us (barrier wait %.1f, epilogues %.1f), producer %.1f us (barrier wait %.1f), tiles %.1f\n",
+            printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  units=%d  clk=%.0f MHz  WS per work-group: consumer %.1f us (barrier wait %.1f, epilogues %.1f), producer %.1f us (barrier wait %.1f, stage %.1f (input wait %.1f), fetch+draw %.1f, vmcnt wait %.1f), tiles %.1f\n",
                    (int)rnd, l.name, ms * 1e3, fl / ms / 1e9, a.tiles_x * a.tiles_y * B * a.nblk, mhz, w[0] / wg / mhz, w[1] / wg / mhz,
-                   w[2] / wg / mhz, w[3] / wg / mhz, w[4] / wg / mhz, w[6] / wg);
+                   w[2] / wg / mhz, w[3] / wg / mhz, w[4] / wg / mhz, w[7] / wg / mhz, w[10] / wg / mhz, w[8] / wg / mhz, w[9] / wg / mhz, w[6] / wg);
         } else
         printf("rnd=%d %-26s %8.1f us  %6.1f TF/s  blocks=%d  clk=%.0f MHz  wg us: prologue %.2f main %.2f epilogue %.2f\n", (int)rnd, l.name, ms * 1e3, fl / ms / 1e9,
                a.tiles_x * a.tiles_y * B * a.nblk, 100.0 * hclk[0] / hclk[1], htim[0] / nw * 0.01, htim[1] / nw * 0.01, htim[2] / nw * 0.01);
