@@ -740,6 +740,8 @@ hipError_t launch_conv_ws(const ConvArgs& args, hipStream_t s) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long units = ntiles * a.nblk;
+    static const int reserve = [] { const char* e = getenv("PPG_CONV_WS_RESERVE"); return e ? std::max(0, atoi(e)) / 8 * 8 : 0; }();
+    cus = std::max(8, cus - reserve);       // CUs left to the kernels of the other streams while this one runs
     long wgs = std::min<long>(cus, (units + 7) / 8 * 8);
     wgs = std::max<long>(8, wgs / 8 * 8);     // a multiple of eight: work-group L serves the band of XCD L % 8
     dim3 grid((unsigned)wgs), block(512);

@@ -243,7 +243,11 @@ struct ppg_ctx {
     int persist_fused = 0, persist_other = 0;
     int xcd_group = 4, xcd_band = 1;   // XCD-aware launch order of the convolutions (ppg::ConvArgs::xcd_group); PPG_XCD_MAP=0 switches it off
     bool persist_forced = false;  // set by PPG_CONV_PERSIST: the numbers apply to every launch, whatever its size
-    bool conv_ws = true;        // PPG_CONV_WS=0: the reduced-precision layers on the one-tile-per-work-group kernel only (the statement the wave-specialised one is checked against)
+    // Which reduced-precision modes run their large 3x3 layers wave-specialised (conv_ws.hip).  Default: mode 1 only, where
+    // the step gains 2-3 %; in mode 3 the step does not move, and in mode 2 (a third of the products) a kernel that takes
+    // every CU for itself costs the other streams' kernels more than it saves.  PPG_CONV_WS=1: every reduced-precision
+    // mode; =0: none (the one-tile-per-work-group kernel the wave-specialised one is checked against).
+    int conv_ws = -1;
     long conv_ws_min_units = 1024;   // (tile, cout block) units a launch needs before it runs wave-specialised (PPG_CONV_WS_MIN)
     bool no_quarter = false;    // PPG_NO_QUARTER_TILES=1: big convolution tiles whatever the batch size (read at ppg_create)
     bool match_matrix = false;  // PPG_MATCH_MATRIX=1: resident matches through the full distance matrix (the path the fused one is checked against)
@@ -692,8 +696,8 @@ void conv_tiling(const ppg_ctx* c, ppg::ConvArgs& a, const DevConv& dc, int mode
     // waves stage the next chunk while its consumer waves multiply (conv_ws.hip).  Launches too small to give every CU a
     // few tiles keep the one-tile-per-work-group kernel.
     a.ws = 0;
-    if (c->conv_ws && a.prec != 0 && dc.ks == 3 && dc.nt == 2 && a.Cin >= 64 && a.Cin % 16 == 0 && a.xcd_group > 0 &&
-        (long)a.tiles_x * a.tiles_y * a.B * a.nblk >= c->conv_ws_min_units && !(mode == ppg::CONV_POOL2 && a.mw != 32))
+    if ((c->conv_ws < 0 ? a.prec == 1 : c->conv_ws != 0) && a.prec != 0 && dc.ks == 3 && dc.nt == 2 && a.Cin >= 64 && a.Cin % 16 == 0 && a.xcd_group > 0 &&
+        (long)a.tiles_x * a.tiles_y * a.B * a.nblk >= c->conv_ws_min_units && a.mw == 32)   // (16 x 16 tiles: measured slower)
         a.ws = 1;
     if (c->no_quarter || fused || a.prec != 0 || dc.ks != 3 || dc.nt != 2) return;
     if ((long)a.tiles_x * a.tiles_y * a.B * a.nblk >= kQuarterBelow) return;
