@@ -94,6 +94,9 @@ def cpu_baseline(H, W, kind, max_num, seconds=12.0):
     return out
 
 
+SWEEP_BATCHES = (1, 2, 4, 8, 16)
+
+
 def batch_sweep(pkg, synth, H, W, args, device_id):
     """Frames/s of the pipelined step at small batches (host images, upload included) and the latency of blocking
     single-frame calls."""
@@ -103,7 +106,7 @@ def batch_sweep(pkg, synth, H, W, args, device_id):
     T = 4
     imgs = [[synth.frame_from_scene(scene[s], H, W, t) for s in range(16)] for t in range(T)]
     rows = []
-    for B in (1, 2, 4, 8, 16):
+    for B in SWEEP_BATCHES:
         ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=args.max_num, device_id=device_id,
                                              precision=args.precision))
         def run(first, count):
@@ -419,6 +422,19 @@ def main():
     sweep = None
     if world == 1 and not args.no_sweep:
         sweep = batch_sweep(pkg, synth, H, W, args, local_rank)
+        if args.precision == 0:
+            # one camera per GPU in the two split modes (descriptors within 1e-3 of the fp32 path): the rows for one and two
+            # frames per call
+            global SWEEP_BATCHES
+            keep = SWEEP_BATCHES
+            SWEEP_BATCHES = (1, 2)
+            try:
+                for mode, key in ((1, "bf16_split_rows"), (3, "f16_split_rows")):
+                    sub = argparse.Namespace(**vars(args))
+                    sub.precision = mode
+                    sweep[key] = batch_sweep(pkg, synth, H, W, sub, local_rank)["rows"]
+            finally:
+                SWEEP_BATCHES = keep
     matchers = None
     if world == 1 and not args.no_sweep and not args.no_cpu_baseline:
         try:
@@ -484,6 +500,10 @@ def main():
                    "CNN 3x3 layers on the fp16 MFMA with scaled hi/lo split operands (3 products), fp32 accumulate")[args.precision]
         kname = ("conv_mfma_kernel<3,2,8,true,32>", "conv_bf16_kernel<2,true,32,3>", "conv_bf16_kernel<2,true,32,1>",
                  "conv_bf16_kernel<2,true,32,3,true>")[args.precision]
+        # the large 3x3 layers of mode 1 run wave-specialised by default (PPG_CONV_WS=1: modes 2 and 3 too, =0: none)
+        ws_env = os.environ.get("PPG_CONV_WS")
+        if args.precision and (ws_env == "1" or (ws_env is None and args.precision == 1)):
+            kname = ("", "conv_ws_kernel<true,32,3,false>", "conv_ws_kernel<true,32,1,false>", "conv_ws_kernel<true,32,3,true>")[args.precision]
         out = {
             "metric": f"front-end frames/sec (extract+describe+match) @{W}x{H}",
             "value": round(frames_total / dt, 2), "unit": "frames/s",
@@ -504,7 +524,8 @@ def main():
                          "frac": round(achieved / peak, 4),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(dom_launches),
                          "flops_per_launch": flops_per_launch, "traffic": None,
-                         "other_3x3_convolutions": {"kernel": "conv_mfma_kernel<3,2,8,false,32|16> (eight launches per step: conv2a-conv4b, the heads' first convolutions in one, EdgeHeatmap block 1)",
+                         "other_3x3_convolutions": {"kernel": ("conv_mfma_kernel<3,2,8,false,32|16>" if args.precision == 0 else "conv_bf16_kernel / conv_ws_kernel, not fused") +
+                                                              " (eight launches per step: conv2a-conv4b, the heads' first convolutions in one, EdgeHeatmap block 1)",
                                                     "achieved": round(other_tf, 2) if other_tf else None,
                                                     "ms_per_step": round(o_ms / nb, 4)},
                          "all_convolutions_achieved": round(all_conv_tf, 2)},

@@ -9,7 +9,7 @@ f=glob.glob('$R/gpurun_out/prof_b1/*/*_kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # last extract: find the last conv1b-fused kernel start
-idx=[i for i,r in enumerate(rows) if 'true, 32' in r['Kernel_Name'] or 'ILi3ELi2ELi8ELb1' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if '8, true' in r['Kernel_Name'] or 'conv_ws_kernel<true' in r['Kernel_Name'] or 'ILi3ELi2ELi8ELb1' in r['Kernel_Name']]
 i0=idx[-1]
 t0=int(rows[i0]['Start_Timestamp'])
 for r in rows[i0-2:]:
