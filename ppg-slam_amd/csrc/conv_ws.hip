@@ -508,7 +508,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(ConvArgs a) {
                 const unsigned long long v = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(gtab[gi * 12 + G_BIAS + 2 * pw]) |
                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(gtab[gi * 12 + G_BIAS + 2 * pw + 1]) << 32);
                 evreg = pw == 1 ? 1.f : pw == 2 ? -0.f : 0.f;    // (no batch norm: v * 1 + -0 is v, bit for bit)
-                if (v) evreg = ((const float*)v)[cb + lane];
+                // (the bias arrays are padded to whole cout blocks, the batch-norm vectors are not: couts past the layer, whose
+                // results are never stored, read its last entry)
+                const int Cout = __builtin_amdgcn_readfirstlane(r[R_COUT]);
+                if (v) evreg = ((const float*)v)[pw == 0 ? cb + lane : min(cb + lane, Cout - 1)];
             }
             if (FUSE1A) {
                 // patch pixel (py, px) = image pixel (y0 - 2 + py, x0 - 2 + px); outside the image the load is given an offset

@@ -274,7 +274,8 @@ def test_wave_specialised_convolutions_equal_plain_ones(pkg, synth, monkeypatch)
     counts do and do not divide evenly, with every layer forced onto the new kernel (PPG_CONV_WS_MIN=8) and with the
     production threshold."""
     cases = ((480, 640, 4, 1, "8"), (480, 640, 3, 3, "8"), (120, 136, 5, 1, "8"), (72, 104, 7, 3, "8"), (96, 128, 2, 2, "8"),
-             (480, 640, 5, 1, None), (240, 320, 1, 1, "8"))
+             (480, 640, 5, 1, None), (240, 320, 1, 1, "8"), (64, 96, 1, 1, "8"), (200, 328, 2, 3, "8"), (480, 640, 1, 2, "8"),
+             (256, 512, 9, 1, None))
     for (H, W, n, prec, ws_min) in cases:
         imgs = [synth.make_frame(H, W, 1310 + k, 0, "dense" if k % 2 else "sparse") for k in range(n)]
         monkeypatch.setenv("PPG_CONV_WS", "0")
@@ -296,6 +297,50 @@ def test_wave_specialised_convolutions_equal_plain_ones(pkg, synth, monkeypatch)
         finally:
             plain.close()
             spec.close()
+
+
+def test_wave_specialised_convolutions_many_batches_in_a_row(pkg, synth, monkeypatch):
+    """The wave-specialised kernel hands tiles, records and LDS stages from wave to wave through barriers and counters: a
+    hazard there would show up now and then, not every time.  Forty 16-frame batches in a row (the production threshold, mode
+    1, frames changing from batch to batch, the pipelined entry points four deep), every network output of every batch
+    bit-identical to the one-tile-per-work-group kernel's."""
+    H, W, n, T = 480, 640, 16, 5
+    scenes = [synth.make_scene(H, W, 4100 + 7 * k, "dense" if k % 3 else "sparse") for k in range(n)]
+    frames = [[synth.frame_from_scene(scenes[k], H, W, t) for k in range(n)] for t in range(T)]
+    monkeypatch.setenv("PPG_CONV_WS", "0")
+    plain = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500, precision=1))
+    monkeypatch.setenv("PPG_CONV_WS", "1")
+    spec = pkg.Context(pkg.default_config(W, H, max_batch=n, max_num=500, precision=1))
+    monkeypatch.delenv("PPG_CONV_WS")
+    try:
+        want = []
+        for t in range(T):
+            plain.extract_batch(frames[t], to_dict=False)
+            want.append([plain.read_tensor(which, f).copy() for which in (pkg.T_FEAT, pkg.T_DESCMAP) for f in (0, n - 1)])
+        for rep in range(40):
+            t = rep % T
+            spec.extract_batch(frames[t], to_dict=False)
+            got = [spec.read_tensor(which, f) for which in (pkg.T_FEAT, pkg.T_DESCMAP) for f in (0, n - 1)]
+            for x, y in zip(want[t], got):
+                assert np.array_equal(x, y), (rep, t)
+        # and through the pipeline, where the convolutions of one batch run beside the post-processing of another
+        ref = [plain.extract_batch(frames[t], to_dict=True) for t in range(T)]
+        done = 0
+        for k in range(24):
+            spec.submit_batch(frames[k % T], match_prev=False)
+            if k - done + 1 >= 4:
+                fr, _, _, cnt = spec.wait_batch(to_dict=True, want_matches=False)
+                for x, y in zip(ref[done % T], fr):
+                    assert np.array_equal(x["xy"], y["xy"]) and np.array_equal(x["desc"], y["desc"]) and np.array_equal(x["edge_idx"], y["edge_idx"]), done
+                done += 1
+        while done < 24:
+            fr, _, _, cnt = spec.wait_batch(to_dict=True, want_matches=False)
+            for x, y in zip(ref[done % T], fr):
+                assert np.array_equal(x["xy"], y["xy"]) and np.array_equal(x["desc"], y["desc"]), done
+            done += 1
+    finally:
+        plain.close()
+        spec.close()
 
 
 def test_tile_walk_equals_one_group_per_tile(pkg, synth, monkeypatch):
