@@ -1,5 +1,5 @@
 // Operand types and the hi/lo splits shared by the reduced-precision convolution kernels (conv_bf16_kernel in
-// ppg_kernels.hip, conv_ws_kernel in conv_ws.hip).
+// conv_kernels.hip, conv_ws_kernel in conv_ws.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,4 +1,4 @@
-// Epilogue shared by the convolution kernels (conv_mfma_kernel, conv_bf16_kernel in ppg_kernels.hip; conv_ws_kernel in
+// Epilogue shared by the convolution kernels (conv_mfma_kernel, conv_bf16_kernel in conv_kernels.hip; conv_ws_kernel in
 // conv_ws.hip).
 #pragma once
 #include <hip/hip_runtime.h>

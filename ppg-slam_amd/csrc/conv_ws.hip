@@ -1,4 +1,4 @@
-// Wave-specialised form of the reduced-precision 3x3 convolution (the arithmetic of conv_bf16_kernel in ppg_kernels.hip:
+// Wave-specialised form of the reduced-precision 3x3 convolution (the arithmetic of conv_bf16_kernel in conv_kernels.hip:
 // operands split into bf16 / fp16 hi + lo, three products per pair, fp32 accumulate; same tile, same operand layouts,
 // same order of the additions, hence the same bits) for launches of many tiles.
 //
@@ -32,7 +32,7 @@ typedef __attribute__((address_space(3))) void* ws_lds_ptr;
 // stay correct: vector-memory operations complete in order, so operations it does not know about only make a wait
 // of its own stronger.
 __device__ __forceinline__ void ws_dma_b128(u32x4 rsrc, unsigned lds_base, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");   // (M0 is written; nothing else in this kernel uses it)
 }
 
 // Every wave of the work-group, once per chunk.  A raw s_barrier (no vmcnt(0): the producers' register loads for the

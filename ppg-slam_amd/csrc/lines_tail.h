@@ -171,7 +171,7 @@ void lines_tail(const ppg_config& cfg, int n, const float* un, const uint32_t* i
         cd.dist = std::sqrt(vx * vx + vy * vy);
         vx = vx / cd.dist; vy = vy / cd.dist;
         // libm-independent statement of std::atan2(float, float): the double function rounded to float (the GPU
-        // statement of this tail, lines_resolve in ppg_kernels.hip, evaluates the same expression)
+        // statement of this tail, line_resolve_kernel in post_kernels.hip, evaluates the same expression)
         cd.dir_ij = (float)std::atan2((double)vy, (double)vx);
         float r = (float)(cd.dir_ij - kPi);
         if (r < -kPi) r = (float)(r + k2Pi);

@@ -1,4 +1,4 @@
-// Launch interface between the host pipeline (ppg_front.cpp) and the gfx950 kernels (ppg_kernels.hip).
+// Launch interface between the host pipeline (ppg_front.cpp) and the gfx950 kernels (conv_kernels.hip, conv_ws.hip, post_kernels.hip, match_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -2,7 +2,7 @@
 // Usage: conv_bench <0 zeros | 1 random | 2 small positive | 3 denormal-range inputs> [batch] [precision 0|1|2|3] [1: wave-specialised kernel]
 #define PPG_CONV_TIMING 1
 #define PPG_WS_TIMING 1
-#include "../../ppg-slam_amd/csrc/ppg_kernels.hip"
+#include "../../ppg-slam_amd/csrc/conv_kernels.hip"
 #include "../../ppg-slam_amd/csrc/conv_ws.hip"
 #include <cstdio>
 #include <cstdlib>
