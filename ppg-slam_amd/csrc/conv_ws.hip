@@ -11,9 +11,11 @@
 //             memory in LDS image order), the input tile through registers (it has to be split into hi/lo on the way;
 //             FUSE1A: it is conv1a of the image patch, evaluated here), and they draw the tiles from per-XCD counters.
 // Two LDS stages; ONE barrier per chunk, which every wave reaches: consumers compute on stage g & 1 while producers fill
-// stage (g + 1) & 1.  The chunk stream runs on across tile boundaries, so a tile's prologue (index set-up, first fetch,
-// image patch) is hidden behind the MFMAs of the tile before it; only the epilogue (bias / batch norm / ReLU / pooling
-// and the stores, with the vectors already in LDS) interrupts the consumers.
+// stage (g + 1) & 1.  The chunk stream runs on across tile boundaries: what a tile needs before its first chunk (its unit,
+// its record, its bias / batch-norm vectors, the image patch, its first input chunk) is requested by the producers five
+// to two steps ahead, and its epilogue (bias / batch norm / ReLU / pooling and the stores) goes out in slices behind the
+// first taps of the NEXT tile, from a copy of the sums.  The MFMA's rows are the pixels and its columns the couts, so
+// that a store instruction writes whole 128-byte lines of the channels-last output.
 #include "ppg_kernels.h"
 #include "conv_split.h"
 #include "conv_store.h"
@@ -41,24 +43,16 @@ __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 #ifdef PPG_WS_TIMING
 // microbenchmark builds only (tools/ubench/conv_bench.hip): shader cycles summed over work-groups:
-// [0] consumer wave 0 in total, [1] of that waiting at the chunk barriers, [2] in epilogues, [3] producer wave 4 in total,
-// [4] of that waiting at the barriers, [5] work-groups, [6] tiles
+// [0] consumer wave 0 in total, [1] of that waiting at the chunk barriers, [2] handing a tile's sums over to the epilogue,
+// [3] producer wave 4 in total, [4] of that waiting at the barriers, [5] work-groups, [6] tiles, [7] producers staging
+// (weights requested, input split and written, next input requested), [8] their per-tile set-up, [9] waiting for the
+// weight pieces, [10] waiting for the input registers
 __device__ unsigned long long* g_ws_timing = nullptr;
 #define WS_T0(var) const long long var = clock64()
 #define WS_ADD(acc, t0) acc += clock64() - (t0)
 #else
 #define WS_T0(var)
 #define WS_ADD(acc, t0)
-#endif
-
-#ifndef WS_TERM_OUTER
-#define WS_TERM_OUTER 1
-#endif
-#ifndef WS_STAGGER
-#define WS_STAGGER 4
-#endif
-#ifndef WS_INTERLEAVE
-#define WS_INTERLEAVE 1
 #endif
 
 template <bool FUSE1A, int MW, int TERMS, bool F16>
@@ -168,18 +162,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(ConvArgs a) {
         return t;
     };
 
-#if WS_STAGGER
-    // The work-groups of a launch would run in step (same start, tiles of equal length): every CU would write its finished
-    // tile at the same moment, and the stores of a whole chip's tiles are a burst the memory system takes several
-    // microseconds to absorb while no CU multiplies.  Starting the work-groups of an XCD a fraction of a tile apart
-    // spreads the stores over the tile's time.
-    {
-        const int phase = (blockIdx.x >> 3) % WS_STAGGER;
-        const long long delay = (long long)phase * nchunks * (200 / WS_STAGGER);    // (100 MHz ticks; a chunk takes about 2 us)
-        const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < delay) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
     // ---------------- prologue (every wave passes the same four barriers) ----------------
     if (tid < 36) gtab[tid] = ((const int*)a.g)[tid];
     if (FUSE1A && wave >= 4) {
@@ -350,7 +332,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (tap + 1 < TAPS) load_ops(ins, ws, tap + 1, ops[(tap + 1) & 1]);
                 const Ops& o = ops[tap & 1];
-#if WS_TERM_OUTER
                 // (every accumulator still sees its three terms in the same order; consecutive MFMAs write different ones)
 #pragma unroll
                 for (int term = (TERMS == 3 ? 0 : 2); term < 3; term++)
@@ -359,19 +340,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
                         for (int n = 0; n < NT; n++)
                             acc[m][n] = term == 0 ? mma(o.wl[n], o.xh[m], acc[m][n]) : term == 1 ? mma(o.wh[n], o.xl[m], acc[m][n]) : mma(o.wh[n], o.xh[m], acc[m][n]);
-#else
-#pragma unroll
-                for (int m = 0; m < 2; m++)
-#pragma unroll
-                    for (int n = 0; n < NT; n++) {
-                        if (TERMS == 3) {
-                            acc[m][n] = mma(o.wl[n], o.xh[m], acc[m][n]);
-                            acc[m][n] = mma(o.wh[n], o.xl[m], acc[m][n]);
-                        }
-                        acc[m][n] = mma(o.wh[n], o.xh[m], acc[m][n]);
-                    }
-#endif
-#if WS_INTERLEAVE
                 // one operand read of the next tap in the shadow of each of the first MFMAs
                 if (tap + 1 < TAPS) {
                     constexpr int READS = TERMS == 3 ? 4 + 2 * NT : 2 + NT, MFMAS = 2 * NT * TERMS;
@@ -379,7 +347,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(ConvArgs a) {
                     for (int i = 0; i < (READS < MFMAS ? READS : MFMAS); i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
                     if (MFMAS > READS) __builtin_amdgcn_sched_group_barrier(0x008, MFMAS - READS, 0);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (decltype(C)::value >= 0 && decltype(C)::value * TAPS + tap < 32) {
                     epi_slice(KIND, decltype(C)::value * TAPS + tap);

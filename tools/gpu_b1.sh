@@ -1,6 +1,7 @@
 #!/bin/bash
 set -o pipefail
 R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/prof_b1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_b1 -- python3 $R/tools/prof_blocking.py ${1:-1} ${2:-0} > $R/gpurun_out/prof_b1.log 2>&1 || { tail -n 20 $R/gpurun_out/prof_b1.log; exit 1; }
 python - <<PY
