@@ -216,6 +216,43 @@ int main(int argc, char** argv) {
         for (auto& kp : F[0].mvKeysUn) conn += kp.mvConnected.size();
         printf("%zu %zu %zu %zu %d %lld\n", F[0].mvKeysUn.size(), F[0].mvKeyEdges.size(), F[1].mvKeysUn.size(), conn, nm, chk);
         if (argc == 7 && projection_demo(matcher, cam, F, argv[6]) != 0) { fprintf(stderr, "cannot write %s\n", argv[6]); return 2; }
+        {   // what another thread of the reference does (LocalMapping.cpp:214, LoopClosing.cpp:408): a Matcher of its own, on a
+            // context without the extractor's weights and buffers; the same match must come out
+            ppg_config mc;
+            ppg_default_config(&mc, W, H);
+            ppg_ctx* mctx = ppg_create_matcher(&mc);
+            if (!mctx) { fprintf(stderr, "ppg_create_matcher: %s\n", ppg_last_error(nullptr)); return 4; }
+            Matcher other(mctx, &cam, 0.9f);
+            std::vector<int> m12b;
+            const int nmb = other.SearchForInitialization(F[0], F[1], prev, m12b, 50);
+            ppg_frame_out none;
+            const bool refused = ppg_extract(mctx, nullptr, 0, &none) == PPG_EINVAL;     // an extractor call on it is an error
+            ppg_destroy(mctx);
+            if (nmb != nm || m12b != m12 || !refused) { fprintf(stderr, "matcher context: %d matches against %d\n", nmb, nm); return 4; }
+        }
+        {   // one process per camera: the barrier between the ranks and the swap of a stereo pair's descriptors, here in a world
+            // of one rank (the partner of the swap is the rank itself).  Skipped when no RCCL can be loaded.
+            uint8_t id[PPG_SHUTTER_ID_BYTES];
+            if (ppg_shutter_unique_id(id) != PPG_OK) {
+                fprintf(stderr, "note: no RCCL (%s): barrier and stereo swap not exercised\n", ppg_last_error(nullptr));
+            } else {
+                ppg_shutter* sh = ppg_shutter_create(ext.context(), 0, 1, id);
+                if (!sh) { fprintf(stderr, "ppg_shutter_create: %s\n", ppg_last_error(ext.context())); return 5; }
+                int released = -2;
+                for (int group = 0; group < 3; group++)
+                    if (ppg_shutter_release(sh, group, nullptr) != PPG_OK) { fprintf(stderr, "ppg_shutter_release: %s\n", ppg_last_error(ext.context())); return 5; }
+                if (ppg_shutter_drain(sh, &released) != PPG_OK || released != 2) { fprintf(stderr, "ppg_shutter_drain: released %d\n", released); return 5; }
+                const int n0 = (int)F[0].mvKeysUn.size();
+                std::vector<float> back((size_t)std::max(n0, 1) * 256);
+                int nback = -1;
+                if (ppg_stereo_swap(sh, 0, n0 ? F[0].mDescriptors.ptr(0) : back.data(), n0, back.data(), &nback) != PPG_OK || nback != n0 ||
+                    (n0 && std::memcmp(back.data(), F[0].mDescriptors.ptr(0), sizeof(float) * 256 * n0) != 0)) {
+                    fprintf(stderr, "ppg_stereo_swap: %d rows back of %d (%s)\n", nback, n0, ppg_last_error(ext.context()));
+                    return 5;
+                }
+                ppg_shutter_destroy(sh);
+            }
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

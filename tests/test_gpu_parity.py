@@ -7,6 +7,8 @@ Three kinds of check:
     reproduce the oracle's integer outputs EXACTLY (same inputs => no rounding excuse);
   * end to end against the oracle / goldens, where near-tied key points may swap (see conftest).
 """
+import re
+
 import numpy as np
 import pytest
 
@@ -979,7 +981,9 @@ def test_host_mirror_program(pkg, synth, tmp_path):
     out = subprocess.run([demo, os.path.dirname(pkg.DEFAULT_WEIGHTS), paths[0], paths[1], str(W), str(H)],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    n0, e0, n1, conn0, nm, chk = [int(v) for v in out.stdout.split()]
+    # (the result line of the demo; RCCL prints a banner of its own to stdout when the demo's barrier section sets it up)
+    line = [ln for ln in out.stdout.splitlines() if re.fullmatch(r"(-?\d+ ){5}-?\d+", ln.strip())][-1]
+    n0, e0, n1, conn0, nm, chk = [int(v) for v in line.split()]
     ctx = get_ctx(pkg, W, H)
     r0, r1 = ctx.extract(imgs[0]), ctx.extract(imgs[1])
     cnt, m12, _ = ctx.search_for_initialization(0.9, r0["desc"], r1["desc"], r1["un"], r0["un"], 50)
