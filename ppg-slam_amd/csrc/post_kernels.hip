@@ -821,6 +821,31 @@ __global__ __launch_bounds__(256) void line_pairs_kernel(LineArgs a) {
     }
 }
 
+// Inclusive prefix sum of one value per thread over a 1024-thread work-group: shuffles inside each wave, the sixteen wave
+// totals through LDS (part: 16 ints), two barriers in all — a work-group barrier of sixteen waves costs about a
+// microsecond, and a doubling scan over the whole work-group has twenty of them.  *total = the sum over all threads.
+__device__ inline int block_incl_scan_1024(int v, int* part, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();   // (an earlier use of part is over)
+    if (lane == 63) part[wave] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int p = part[w];
+        tot += p;
+        if (w < wave) base += p;
+    }
+    *total = tot;
+    return base + x;
+}
+
 // exclusive scan of the per-row counts of one frame (n <= 4096 rows), total -> counters[2]
 __global__ __launch_bounds__(1024) void line_scan_kernel(LineArgs a) {
     __shared__ int part[1024];
@@ -834,20 +859,13 @@ __global__ __launch_bounds__(1024) void line_scan_kernel(LineArgs a) {
         const int r = tid * per + k;
         if (r < n) local += rowcnt[r];
     }
-    part[tid] = local;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-        const int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = part[tid] - local;
+    int total;
+    int run = block_incl_scan_1024(local, part, &total) - local;
     for (int k = 0; k < per; k++) {
         const int r = tid * per + k;
         if (r < n) { const int c = rowcnt[r]; rowcnt[r] = run; run += c; }
     }
-    if (tid == 1023) cnt[2] = part[1023];
+    if (tid == 1023) cnt[2] = total;
 }
 
 // Sixteen lanes per candidate: the samples of a line are evaluated sixteen at a time (the loads and the bilinear
@@ -1012,20 +1030,12 @@ __device__ inline int block_scan_1024(int* arr, int n, int* part) {
         const int r = tid * per + k;
         if (r < n) local += arr[r];
     }
-    part[tid] = local;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = part[tid] - local;
+    int total;
+    int run = block_incl_scan_1024(local, part, &total) - local;
     for (int k = 0; k < per; k++) {
         const int r = tid * per + k;
         if (r < n) { const int c = arr[r]; arr[r] = run; run += c; }
     }
-    const int total = part[1023];
     __syncthreads();
     return total;
 }
@@ -1418,17 +1428,10 @@ __global__ __launch_bounds__(1024) void line_resolve_kernel(LineTailArgs a) {
         }
     }
     const int mine_cnt = __popcll(keepm);
-    part[tid] = mine_cnt;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
-        const int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    const int ebase = part[1023];
+    int ebase;
+    const int mine_end = block_incl_scan_1024(mine_cnt, part, &ebase);
     {
-        int e = part[tid] - mine_cnt;
+        int e = mine_end - mine_cnt;
         unsigned long long m = keepm;
         while (m) {
             const int i = __ffsll((long long)m) - 1;
