@@ -2,7 +2,7 @@
 frames that bench.py replays (640 x 480, JUNCTION_MAX_NUM = 1024), every stream matched frame to frame.  Per mode (1: bf16
 hi/lo split, 3: fp16 hi/lo split) against mode 0 (fp32, the parity path): the share of frames whose key-point list, edge
 list and match vector are identical, and the largest descriptor distance at a common key point, which must stay inside
-the 1e-3 bar.  Prints the table that DESIGN.md quotes."""
+the 1e-3 bar.  Prints the table and writes it to gpurun_out/precision_stats.json."""
 import json
 import os
 
