@@ -349,7 +349,11 @@ def main():
         the collection of k overlap); every collected group passes the global-shutter barrier (non-blocking all-reduce),
         and the barriers still in flight are waited for before the step count is complete."""
         streams_mod.run_steps(submit, wait, shutter, first, count, depth=4)
-        shutter.drain()
+        last = shutter.drain()
+        # every rank runs the same steps: the newest group finished on all of them must be this rank's newest
+        if count > 0 and last != first + count - 1:
+            raise RuntimeError("rank %d: the barrier released group %d, this rank finished %d: the ranks are out of step"
+                               % (rank, last, first + count - 1))
 
     # The first second of sustained load runs 5-10 % slower than the steady state (clock and power ramp of an
     # idle GPU, first-touch of the pinned result rings): an untimed pre-roll makes sure that at least PREROLL
