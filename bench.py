@@ -320,6 +320,17 @@ def main():
     if shutter is None:
         shutter = streams_mod.ShutterBarrier(dist, "cuda", single_rank_too=force_dist)
 
+    class GroupNumbers:
+        """The passes of this run restart their frame index; the barrier gets one ascending group number over all of them."""
+        next = 0
+
+        def release(self, _k):
+            r = shutter.release(self.next)
+            self.next += 1
+            return r
+
+    groups = GroupNumbers()
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -348,12 +359,12 @@ def main():
         """`count` steps, software-pipelined four deep (the CNN of batches k+3 and k+2, the post-processing of k+1 and
         the collection of k overlap); every collected group passes the global-shutter barrier (non-blocking all-reduce),
         and the barriers still in flight are waited for before the step count is complete."""
-        streams_mod.run_steps(submit, wait, shutter, first, count, depth=4)
+        streams_mod.run_steps(submit, wait, groups, first, count, depth=4)
         last = shutter.drain()
         # every rank runs the same steps: the newest group finished on all of them must be this rank's newest
-        if count > 0 and last != first + count - 1:
+        if count > 0 and last != groups.next - 1:
             raise RuntimeError("rank %d: the barrier released group %d, this rank finished %d: the ranks are out of step"
-                               % (rank, last, first + count - 1))
+                               % (rank, last, groups.next - 1))
 
     # The first second of sustained load runs 5-10 % slower than the steady state (clock and power ramp of an
     # idle GPU, first-touch of the pinned result rings): an untimed pre-roll makes sure that at least PREROLL

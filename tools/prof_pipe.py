@@ -21,13 +21,19 @@ frames = [[synth.frame_from_scene(scenes[s], H, W, t) for s in range(B)] for t i
 depth = 4
 ctx.extract_batch(frames[0], to_dict=False)
 t0 = time.perf_counter()
+t_sub = t_wait = 0.0
 for t in range(steps + depth):
     if t < steps:
+        ta = time.perf_counter()
         ctx.submit_batch(frames[t % 8], match_prev=True)
+        t_sub += time.perf_counter() - ta
     if t >= depth - 1 and t - (depth - 1) < steps:
+        ta = time.perf_counter()
         ctx.wait_batch(to_dict=False)
+        t_wait += time.perf_counter() - ta
 dt = time.perf_counter() - t0
-print("B=%d: %.1f frames/s, %.3f ms per step" % (B, B * steps / dt, 1e3 * dt / steps))
+print("B=%d: %.1f frames/s, %.3f ms per step (host: %.3f ms in submit_batch, %.3f ms in wait_batch per step)"
+      % (B, B * steps / dt, 1e3 * dt / steps, 1e3 * t_sub / steps, 1e3 * t_wait / steps))
 ctx.close()
 if idle is not None:
     idle.close()
