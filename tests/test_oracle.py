@@ -407,3 +407,88 @@ def test_line_graph_sensitivity_to_libm_reading(orc, onet, synth, capsys):
         report.append(f"{name}: {len(a)} edges, float-vs-double libm reading: identical; integer abs changes {len(a ^ b)} edges")
     with capsys.disabled():
         print("\n" + "\n".join(report))
+
+
+def _distances_in_order(a, B, packet, fused):
+    """fp32 `(a - b).norm()` of one row against every row of B with the squares added in a given order: `packet` = 0 is
+    the sequential chain d = 0..255; 4, 8 and 16 are Eigen's vectorised reduction for SSE, AVX and AVX-512 packets (two
+    packet accumulators over alternating packets, their sum, then the halving horizontal add; Eigen/src/Core/Redux.h and
+    the architectures' predux).  `fused`: the square goes into the sum without a rounding of its own (a compiler that
+    contracts to FMA; the product of two floats is exact in double)."""
+    f32, f64 = np.float32, np.float64
+    d = (B - a[None, :]).astype(f32)
+
+    def add_sq(p, x):
+        if fused:
+            return (p.astype(f64) + x.astype(f64) * x.astype(f64)).astype(f32)
+        return (p + (x * x).astype(f32)).astype(f32)
+
+    if packet == 0:
+        s = np.zeros(d.shape[0], f32)
+        for k in range(d.shape[1]):
+            s = add_sq(s, d[:, k])
+        return np.sqrt(s).astype(f32)
+    P = packet
+    p0, p1 = (d[:, 0:P] * d[:, 0:P]).astype(f32), (d[:, P:2 * P] * d[:, P:2 * P]).astype(f32)
+    for i in range(2 * P, d.shape[1], 2 * P):
+        p0, p1 = add_sq(p0, d[:, i:i + P]), add_sq(p1, d[:, i + P:i + 2 * P])
+    p = (p0 + p1).astype(f32)
+    while p.shape[1] > 4:
+        h = p.shape[1] // 2
+        p = (p[:, :h] + p[:, h:]).astype(f32)
+    s = ((p[:, 0] + p[:, 2]).astype(f32) + (p[:, 1] + p[:, 3]).astype(f32)).astype(f32)
+    return np.sqrt(s).astype(f32)
+
+
+def _all_pairs_claim_match(D, th, ratio):
+    """Matcher::SearchForInitialization (matching/src/Matcher.cpp:582-651) with a window that holds every feature, on a
+    given distance matrix: rows in order, best and second over the columns not yet claimed (an accepted distance is
+    stored in a vector<int>, :588, so a claimed column is never looked at again), accepted iff best <= th and
+    best < ratio * second."""
+    n1, n2 = D.shape
+    claimed = np.zeros(n2, bool)
+    m = np.full(n1, -1, np.int32)
+    for i in range(n1):
+        row = np.where(claimed, np.float32(np.inf), D[i])
+        j = int(np.argmin(row))
+        best = row[j]
+        row[j] = np.inf
+        if best <= np.float32(th) and best < np.float32(ratio) * row.min():
+            m[i] = j
+            claimed[j] = True
+    return m
+
+
+@pytest.mark.parametrize("name", ["full_480x640_s1_sparse.npz", "full_480x640_s11_dense.npz"])
+def test_match_indices_do_not_depend_on_the_distance_summation_order(name, orc, capsys):
+    """DescriptorDistance is `(des1 - des2).norm()` on Eigen maps (feature/src/MapPoint.cpp:22-29): the order in which Eigen
+    adds the 256 squares depends on the instruction set it was compiled for and cannot be pinned without Eigen.  Oracle,
+    library and kernels define it as the sequential fused chain.  This measures what the choice can change: the all-pairs
+    claim match of the two golden frames is evaluated on distance matrices built in every order Eigen can use (SSE, AVX and
+    AVX-512 packets, with and without contraction to FMA), the plain sequential sum and the correctly rounded one; the
+    sequential fused chain must reproduce the stored matches of the oracle, and every other order the same index vector."""
+    g = golden(name)
+    A, B = g["kp_desc_0"], g["kp_desc_1"]
+    orders = [("sequential, fused (the definition)", 0, True), ("sequential", 0, False), ("SSE packets", 4, False),
+              ("SSE packets, fused", 4, True), ("AVX packets", 8, False), ("AVX packets, fused", 8, True),
+              ("AVX-512 packets", 16, False)]
+    mats = []
+    for label, packet, fused in orders:
+        mats.append((label, np.stack([_distances_in_order(A[i], B, packet, fused) for i in range(A.shape[0])])))
+    exact = np.sqrt(((A[:, None, :].astype(np.float64) - B[None, :, :].astype(np.float64)) ** 2).sum(2)).astype(np.float32)
+    mats.append(("correctly rounded", exact))
+    ref = mats[0][1]
+    # the emulated definition is the oracle's own chain, bit for bit
+    for i in (0, 7, A.shape[0] - 1):
+        for j in (0, 3, B.shape[0] - 1):
+            assert ref[i, j] == np.float32(orc.descriptor_distance(A[i], B[j]))
+    m_ref = _all_pairs_claim_match(ref, 0.7, 0.9)
+    assert np.array_equal(m_ref, g["m12_all"])
+    report = []
+    for label, D in mats[1:]:
+        m = _all_pairs_claim_match(D, 0.7, 0.9)
+        report.append(f"{name}: {label}: max |difference of a distance| {float(np.abs(D - ref).max()):.2e}, "
+                      f"{int((m != m_ref).sum())} of {len(m)} match indices differ")
+        assert np.array_equal(m, m_ref), label
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
