@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU path: stream sharding and the global-shutter barrier."""
+"""gloo tests (world sizes 2 and 4) of the multi-GPU path: stream sharding, the global-shutter barrier, the step loop."""
 import importlib
 import os
 import socket
@@ -133,8 +133,9 @@ def _loop_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_step_loop_barrier_counts_two_ranks():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_step_loop_barrier_counts(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_loop_worker, args=(r, world, port, q)) for r in range(world)]
