@@ -122,6 +122,49 @@ def test_ragged_sizes_vs_oracle(pkg, orc, onet, synth):
         assert float(np.linalg.norm(r["desc"] - d, axis=1).max()) < 1e-5
 
 
+def test_smallest_image_sizes_vs_oracle(pkg, orc, onet):
+    """The smallest images ppg_create accepts (sides of 16 and up, multiples of 8), one and three frames per call: a
+    feature map of 2 x 2 cells, images narrower than a convolution tile, the 4-pixel border leaving room for no key
+    point at all.  Network outputs within the fp32 band of the oracle's, key points, edges, adjacency, collinear pairs
+    equal, N = 0 where the oracle finds nothing."""
+    rng = np.random.default_rng(5)
+
+    def scene(H, W):
+        img = np.full((H, W), 128, np.uint8)
+        for _ in range(max(2, H * W // 400)):
+            y0, x0 = int(rng.integers(0, H - 3)), int(rng.integers(0, W - 3))
+            h, w = int(rng.integers(3, max(4, H // 2))), int(rng.integers(3, max(4, W // 2)))
+            img[y0:y0 + h, x0:x0 + w] = int(rng.integers(0, 256))
+        return img
+
+    found = 0
+    for (H, W) in ((16, 16), (16, 32), (24, 40), (32, 16), (40, 24), (16, 200), (200, 16), (48, 48), (56, 72)):
+        for B in (1, 3):
+            imgs = [scene(H, W) for _ in range(B)]
+            ctx = pkg.Context(pkg.default_config(W, H, max_batch=B, max_num=500))
+            try:
+                outs = ctx.extract_batch(imgs)
+                feat = [ctx.read_tensor(pkg.T_FEAT, b) for b in range(B)]
+                junc = [ctx.read_tensor(pkg.T_JUNC, b) for b in range(B)]
+            finally:
+                ctx.close()
+            for b in range(B):
+                t = onet.inference(imgs[b])
+                assert float(np.abs(feat[b] - nhwc(t["feat"])).max()) <= 4e-6 * max(float(np.abs(t["feat"]).max()), 1.0), (H, W, B, b)
+                assert float(np.abs(junc[b] - nhwc(t["junc"])).max()) <= 4e-6 * max(float(np.abs(t["junc"]).max()), 1.0), (H, W, B, b)
+                o = orc.extract(onet, orc.default_cfg(W, H, 500), imgs[b])
+                r = outs[b]
+                assert r["n"] == o["n"], (H, W, B, b)
+                if o["n"] == 0:
+                    continue
+                found += r["n"]
+                assert np.array_equal(r["xy"], o["xy"]) and np.array_equal(r["out"], o["out"]), (H, W, B, b)
+                assert np.array_equal(r["edge_idx"], o["edge_idx"]) and np.array_equal(r["conn_idx"], o["conn_idx"]), (H, W, B, b)
+                assert np.array_equal(r["coline_pairs"], o["coline_pairs"]), (H, W, B, b)
+                assert float(np.linalg.norm(r["desc"] - o["desc"], axis=1).max()) < 1e-5, (H, W, B, b)
+    assert found > 20
+
+
 def test_end_to_end_vs_oracle_random_scenes(pkg, orc, synth):
     """Whole frames, image in -> key points, edges, adjacency, collinear pairs, descriptors out, against the oracle running
     its own convolutions and its own libm, over a set of random sizes, scenes and JUNCTION_MAX_NUM values.  The two
