@@ -433,6 +433,20 @@ int ppg_shutter_stats(const ppg_shutter* sh, long long* started, int* pending);
  * desc: n rows of 256 floats (host); partner_desc: room for junction_max_num rows (host); *n_partner = rows received.
  * Both sides call it for every frame, with contexts of the same junction_max_num.  Blocks until the swap is done. */
 int ppg_stereo_swap(ppg_shutter* sh, int partner, const float* desc, int n, float* partner_desc, int* n_partner);
+/* The same swap and the left-right match in one call, for a frame whose descriptors are still on the GPU: frame `frame` of the
+ * batch that the last ppg_extract* / ppg_wait_batch on the shutter's context handed out (valid until the second
+ * ppg_submit_batch* after that call).  The rows go GPU to GPU (nothing of them crosses PCIe), and this side's rows are
+ * matched against the partner's as Matcher::SearchForInitialization does with a window that holds every feature
+ * (matching/src/Matcher.cpp:582-651: all pairs, TH_LOW, `nnratio`), on a matcher context and stream of the shutter's own,
+ * beside the extraction pipeline.  matches12: junction_max_num entries (-1 beyond this frame's key points);
+ * n_matches, n_partner may be NULL.  Both sides call it for every frame.  Blocks until the result is in place.
+ * The reference has no counterpart (one process, one device; its stereo matching happens on the host). */
+int ppg_stereo_match(ppg_shutter* sh, int partner, int frame, float nnratio, int32_t* matches12, int* n_matches, int* n_partner);
+/* The two halves of ppg_stereo_match for a loop that must not wait: _start enqueues swap and match and returns, _finish
+ * waits for them and hands out the result (typically one frame later).  One match at a time per shutter; ppg_stereo_swap
+ * shares its buffers and is refused in between. */
+int ppg_stereo_match_start(ppg_shutter* sh, int partner, int frame, float nnratio);
+int ppg_stereo_match_finish(ppg_shutter* sh, int32_t* matches12, int* n_matches, int* n_partner);
 
 #ifdef __cplusplus
 }

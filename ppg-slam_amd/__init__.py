@@ -131,6 +131,9 @@ def lib():
         L.ppg_shutter_drain.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ppg_shutter_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
         L.ppg_stereo_swap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.ppg_stereo_match.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ppg_stereo_match_start.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.ppg_stereo_match_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ppg_create.restype = C.c_void_p
         L.ppg_create.argtypes = [C.POINTER(Config)]
         L.ppg_destroy.argtypes = [C.c_void_p]

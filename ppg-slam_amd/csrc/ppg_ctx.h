@@ -222,6 +222,7 @@ struct ppg_ctx {
     // the step gains 2-3 %; in mode 3 the step does not move, and in mode 2 (a third of the products) a kernel that takes
     // every CU for itself costs the other streams' kernels more than it saves.  PPG_CONV_WS=1: every reduced-precision
     // mode; =0: none (the one-tile-per-work-group kernel the wave-specialised one is checked against).
+    int last_out_slot = -1, last_out_n = 0;   // the slot and frame count the last ppg_extract* / ppg_wait_batch handed out
     int conv_ws = -1;
     long conv_ws_min_units = 1024;   // (tile, cout block) units a launch needs before it runs wave-specialised (PPG_CONV_WS_MIN)
     bool no_quarter = false;    // PPG_NO_QUARTER_TILES=1: big convolution tiles whatever the batch size (read at ppg_create)
@@ -240,8 +241,7 @@ PPG_HIDDEN void prof_resolve(ppg_ctx* c);
 PPG_HIDDEN bool any_inflight(const ppg_ctx* c);
 // (defined in ppg_match.cpp)
 PPG_HIDDEN int scratch_setup(ppg_ctx* c, int dev);   // where this GPU keeps the work array of ppg_match_nn_noalloc; once per device
-extern "C" PPG_HIDDEN int match_resident(ppg_ctx* c, const float* dA, const int* nA, const float* dB, const int* nB, int batch,
-                              float nnratio, int32_t* d_match, int* d_mcounts);
+// (match_resident: declared in ppg_internal.h)
 
 #define HIPCHK(c, expr)                                                                              \
     do {                                                                                             \

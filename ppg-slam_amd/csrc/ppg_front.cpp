@@ -487,6 +487,27 @@ int ppg_set_error(ppg_ctx* c, int code, const char* fmt, ...) {
 }
 int ppg_ctx_device(const ppg_ctx* c) { return c->cfg.device_id; }
 int ppg_ctx_max_num(const ppg_ctx* c) { return c->maxn; }
+const ppg_config* ppg_ctx_config(const ppg_ctx* c) { return &c->cfg; }
+void* ppg_ctx_match_stream(ppg_ctx* c) { return (void*)c->match_stream; }
+int ppg_ctx_raise_match_stream(ppg_ctx* c) {
+    int lo = 0, hi = 0;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(c, hipStreamSynchronize(c->match_stream));
+    HIPCHK(c, hipStreamDestroy(c->match_stream));
+    c->match_stream = nullptr;
+    HIPCHK(c, hipStreamCreateWithPriority(&c->match_stream, hipStreamNonBlocking, hi));
+    return PPG_OK;
+}
+int ppg_ctx_last_desc(ppg_ctx* c, int frame, const float** d_desc, int* n) {
+    if (c->matcher_only || c->last_out_slot < 0)
+        return fail(c, PPG_EINVAL, "no extracted batch is resident: call ppg_extract* or ppg_wait_batch first");
+    if (frame < 0 || frame >= c->last_out_n) return fail(c, PPG_EINVAL, "frame %d outside the %d frames of the last batch", frame, c->last_out_n);
+    const Slot& sl = c->slot[c->last_out_slot];
+    *d_desc = sl.desc + (size_t)frame * c->maxn * 256;
+    *n = sl.nkp[frame];
+    return PPG_OK;
+}
 
 extern "C" {
 
@@ -1035,6 +1056,7 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
                 k[0], k[7] & 255, k[1], k[2], k[3], k[4], k[6], k[7] >> 8);
     }
     for (int b = 0; b < n; b++) sl.nkp[b] = sl.h_counters[b * 8 + 3];
+    c->last_out_slot = si; c->last_out_n = n;
     const double t_tail0 = now_ms();
     const int M1 = M + 1;
     // Frames whose line graph the device tail finished point straight into the pinned mirrors.  The others (a value

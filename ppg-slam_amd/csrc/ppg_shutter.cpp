@@ -90,6 +90,14 @@ struct ppg_shutter {
     // stereo swap: [max_num][256] floats + 64 floats whose first carries the row count
     float *d_send = nullptr, *d_recv = nullptr, *h_send = nullptr, *h_recv = nullptr;
     size_t swap_floats = 0;
+    // resident left-right match (ppg_stereo_match): a matcher context of the shutter's own, so that the match neither
+    // queues behind the pipeline's matches nor shares their work arrays
+    ppg_ctx* mctx = nullptr;
+    hipEvent_t ev_swap = nullptr;
+    int32_t *d_match = nullptr, *h_match = nullptr;
+    int *d_mcount = nullptr, *h_mcount = nullptr;
+    bool match_pending = false;   // a ppg_stereo_match_start whose result has not been fetched
+    int match_rows = 0, match_partner = 0;
 };
 
 namespace {
@@ -148,6 +156,35 @@ int swap_buffers(ppg_shutter* sh) {
     return PPG_OK;
 }
 
+int match_buffers(ppg_shutter* sh) {
+    if (sh->mctx) return PPG_OK;
+    ppg_config cfg = *ppg_ctx_config(sh->ctx);
+    ppg_ctx* m = ppg_create_matcher(&cfg);
+    if (!m) return ppg_set_error(sh->ctx, PPG_EHIP, "ppg_stereo_match: %s", ppg_last_error(nullptr));
+    sh->mctx = m;
+    // a caller waits for this match, so its kernels go to a stream of the highest priority (on the matcher contexts' usual
+    // low-priority stream a call lasts 1 ms beside a running pipeline instead of 0.2 ms)
+    if (ppg_ctx_raise_match_stream(m) != PPG_OK)
+        return ppg_set_error(sh->ctx, PPG_EHIP, "ppg_stereo_match: %s", ppg_last_error(m));
+    SH_HIP(sh, hipEventCreateWithFlags(&sh->ev_swap, hipEventDisableTiming));
+    SH_HIP(sh, hipMalloc((void**)&sh->d_match, sizeof(int32_t) * sh->max_num));
+    SH_HIP(sh, hipMalloc((void**)&sh->d_mcount, sizeof(int) * 8));
+    SH_HIP(sh, hipHostMalloc((void**)&sh->h_match, sizeof(int32_t) * sh->max_num, hipHostMallocDefault));
+    SH_HIP(sh, hipHostMalloc((void**)&sh->h_mcount, sizeof(int) * 8, hipHostMallocDefault));
+    return PPG_OK;
+}
+
+// one fixed-size message each way on the shutter's stream: [max_num][256] floats, then 64 floats whose first holds the row count
+int exchange(ppg_shutter* sh, int partner) {
+    SH_NCCL(sh, sh->r->GroupStart());
+    const ncclResult_t e1 = sh->r->Send(sh->d_send, sh->swap_floats, ncclFloat, partner, sh->comm, sh->stream);
+    const ncclResult_t e2 = sh->r->Recv(sh->d_recv, sh->swap_floats, ncclFloat, partner, sh->comm, sh->stream);
+    SH_NCCL(sh, sh->r->GroupEnd());
+    SH_NCCL(sh, e1);
+    SH_NCCL(sh, e2);
+    return PPG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -193,6 +230,12 @@ void ppg_shutter_destroy(ppg_shutter* sh) {
     if (sh->d_val) (void)hipFree(sh->d_val);
     if (sh->h_in) (void)hipHostFree(sh->h_in);
     if (sh->h_out) (void)hipHostFree(sh->h_out);
+    if (sh->mctx) ppg_destroy(sh->mctx);
+    if (sh->ev_swap) (void)hipEventDestroy(sh->ev_swap);
+    if (sh->d_match) (void)hipFree(sh->d_match);
+    if (sh->d_mcount) (void)hipFree(sh->d_mcount);
+    if (sh->h_match) (void)hipHostFree(sh->h_match);
+    if (sh->h_mcount) (void)hipHostFree(sh->h_mcount);
     if (sh->d_send) (void)hipFree(sh->d_send);
     if (sh->d_recv) (void)hipFree(sh->d_recv);
     if (sh->h_send) (void)hipHostFree(sh->h_send);
@@ -249,6 +292,8 @@ int ppg_stereo_swap(ppg_shutter* sh, int partner, const float* desc, int n, floa
     if (partner < 0 || partner >= sh->world || n < 0 || n > sh->max_num || (n && !desc) || !partner_desc || !n_partner)
         return ppg_set_error(sh->ctx, PPG_EINVAL, "ppg_stereo_swap: bad argument (partner %d of %d ranks, %d rows, at most %d)",
                              partner, sh->world, n, sh->max_num);
+    if (sh->match_pending)
+        return ppg_set_error(sh->ctx, PPG_EINVAL, "ppg_stereo_swap: a started match still uses the swap buffers (ppg_stereo_match_finish)");
     SH_HIP(sh, hipSetDevice(sh->device));
     int rc = swap_buffers(sh);
     if (rc) return rc;
@@ -259,12 +304,8 @@ int ppg_stereo_swap(ppg_shutter* sh, int partner, const float* desc, int n, floa
     memcpy(sh->h_send + rows, &cnt, sizeof(int));
     if (n) SH_HIP(sh, hipMemcpyAsync(sh->d_send, sh->h_send, sizeof(float) * 256 * (size_t)n, hipMemcpyHostToDevice, sh->stream));
     SH_HIP(sh, hipMemcpyAsync(sh->d_send + rows, sh->h_send + rows, sizeof(float) * 64, hipMemcpyHostToDevice, sh->stream));
-    SH_NCCL(sh, sh->r->GroupStart());
-    const ncclResult_t e1 = sh->r->Send(sh->d_send, sh->swap_floats, ncclFloat, partner, sh->comm, sh->stream);
-    const ncclResult_t e2 = sh->r->Recv(sh->d_recv, sh->swap_floats, ncclFloat, partner, sh->comm, sh->stream);
-    SH_NCCL(sh, sh->r->GroupEnd());
-    SH_NCCL(sh, e1);
-    SH_NCCL(sh, e2);
+    rc = exchange(sh, partner);
+    if (rc) return rc;
     SH_HIP(sh, hipMemcpyAsync(sh->h_recv, sh->d_recv, sizeof(float) * sh->swap_floats, hipMemcpyDeviceToHost, sh->stream));
     SH_HIP(sh, hipStreamSynchronize(sh->stream));
     int m = 0;
@@ -275,6 +316,70 @@ int ppg_stereo_swap(ppg_shutter* sh, int partner, const float* desc, int n, floa
     if (m) memcpy(partner_desc, sh->h_recv, sizeof(float) * 256 * (size_t)m);
     *n_partner = m;
     return PPG_OK;
+}
+
+int ppg_stereo_match_start(ppg_shutter* sh, int partner, int frame, float nnratio) {
+    if (!sh) return PPG_EINVAL;
+    if (partner < 0 || partner >= sh->world)
+        return ppg_set_error(sh->ctx, PPG_EINVAL, "ppg_stereo_match: bad argument (partner %d of %d ranks)", partner, sh->world);
+    if (sh->match_pending)
+        return ppg_set_error(sh->ctx, PPG_EINVAL, "ppg_stereo_match_start: the previous match was not fetched (ppg_stereo_match_finish)");
+    SH_HIP(sh, hipSetDevice(sh->device));
+    const float* d_desc = nullptr;
+    int n = 0;
+    int rc = ppg_ctx_last_desc(sh->ctx, frame, &d_desc, &n);
+    if (!rc) rc = swap_buffers(sh);
+    if (!rc) rc = match_buffers(sh);
+    if (rc) return rc;
+    const size_t rows = (size_t)sh->max_num * 256;
+    // this side's rows never leave the GPU: slot -> send buffer, the count behind them
+    if (n) SH_HIP(sh, hipMemcpyAsync(sh->d_send, d_desc, sizeof(float) * 256 * (size_t)n, hipMemcpyDeviceToDevice, sh->stream));
+    memcpy(sh->h_send + rows, &n, sizeof(int));
+    SH_HIP(sh, hipMemcpyAsync(sh->d_send + rows, sh->h_send + rows, sizeof(float) * 64, hipMemcpyHostToDevice, sh->stream));
+    rc = exchange(sh, partner);
+    if (rc) return rc;
+    SH_HIP(sh, hipMemcpyAsync(sh->h_recv + rows, sh->d_recv + rows, sizeof(float) * 64, hipMemcpyDeviceToHost, sh->stream));
+    SH_HIP(sh, hipEventRecord(sh->ev_swap, sh->stream));
+    // Matcher::SearchForInitialization with a window that holds every feature (matching/src/Matcher.cpp:582-651), left rows =
+    // this side's, on the matcher context's stream behind the swap; the counts are the ints in the two message tails
+    hipStream_t ms = (hipStream_t)ppg_ctx_match_stream(sh->mctx);
+    SH_HIP(sh, hipStreamWaitEvent(ms, sh->ev_swap, 0));
+    rc = match_resident(sh->mctx, sh->d_send, (const int*)(sh->d_send + rows), sh->d_recv, (const int*)(sh->d_recv + rows), 1,
+                        nnratio, sh->d_match, sh->d_mcount);
+    if (rc) return ppg_set_error(sh->ctx, rc, "ppg_stereo_match: %s", ppg_last_error(sh->mctx));
+    SH_HIP(sh, hipMemcpyAsync(sh->h_match, sh->d_match, sizeof(int32_t) * sh->max_num, hipMemcpyDeviceToHost, ms));
+    SH_HIP(sh, hipMemcpyAsync(sh->h_mcount, sh->d_mcount, sizeof(int), hipMemcpyDeviceToHost, ms));
+    sh->match_pending = true;
+    sh->match_rows = n;
+    sh->match_partner = partner;
+    return PPG_OK;
+}
+
+int ppg_stereo_match_finish(ppg_shutter* sh, int32_t* matches12, int* n_matches, int* n_partner) {
+    if (!sh) return PPG_EINVAL;
+    if (!matches12) return ppg_set_error(sh->ctx, PPG_EINVAL, "ppg_stereo_match_finish: matches12 is NULL");
+    if (!sh->match_pending) return ppg_set_error(sh->ctx, PPG_EINVAL, "ppg_stereo_match_finish: no match was started");
+    SH_HIP(sh, hipSetDevice(sh->device));
+    sh->match_pending = false;
+    SH_HIP(sh, hipStreamSynchronize(sh->stream));
+    SH_HIP(sh, hipStreamSynchronize((hipStream_t)ppg_ctx_match_stream(sh->mctx)));
+    const size_t rows = (size_t)sh->max_num * 256;
+    int m = 0;
+    memcpy(&m, sh->h_recv + rows, sizeof(int));
+    if (m < 0 || m > sh->max_num)
+        return ppg_set_error(sh->ctx, PPG_ECOMM, "ppg_stereo_match: partner %d announced %d rows (its junction_max_num must equal this side's %d)",
+                             sh->match_partner, m, sh->max_num);
+    for (int i = 0; i < sh->max_num; i++) matches12[i] = i < sh->match_rows ? sh->h_match[i] : -1;
+    if (n_matches) *n_matches = sh->h_mcount[0];
+    if (n_partner) *n_partner = m;
+    return PPG_OK;
+}
+
+int ppg_stereo_match(ppg_shutter* sh, int partner, int frame, float nnratio, int32_t* matches12, int* n_matches, int* n_partner) {
+    if (!sh) return PPG_EINVAL;
+    if (!matches12) return ppg_set_error(sh->ctx, PPG_EINVAL, "ppg_stereo_match: matches12 is NULL");
+    const int rc = ppg_stereo_match_start(sh, partner, frame, nnratio);
+    return rc ? rc : ppg_stereo_match_finish(sh, matches12, n_matches, n_partner);
 }
 
 }  // extern "C"

@@ -119,6 +119,28 @@ class Shutter:
                                          out.ctypes.data_as(C.c_void_p), C.byref(m)))
         return out[:m.value].copy()
 
+    def stereo_match(self, partner, frame=0, nnratio=0.9):
+        """ppg_stereo_match: swaps the resident descriptors of `frame` of the last collected batch with `partner` and matches
+        this side's rows against the partner's on the GPU.  Returns (matches12[max_num], n_matches, n_partner)."""
+        M = int(self.ctx.cfg.junction_max_num)
+        m12 = np.full(M, -1, np.int32)
+        cnt, npart = C.c_int(0), C.c_int(0)
+        self._chk(self.L.ppg_stereo_match(C.c_void_p(self.h), int(partner), int(frame), C.c_float(nnratio),
+                                          m12.ctypes.data_as(C.c_void_p), C.byref(cnt), C.byref(npart)))
+        return m12, cnt.value, npart.value
+
+    def stereo_match_start(self, partner, frame=0, nnratio=0.9):
+        """ppg_stereo_match_start: enqueues swap and match, returns at once."""
+        self._chk(self.L.ppg_stereo_match_start(C.c_void_p(self.h), int(partner), int(frame), C.c_float(nnratio)))
+
+    def stereo_match_finish(self):
+        """ppg_stereo_match_finish: (matches12[max_num], n_matches, n_partner) of the started match."""
+        M = int(self.ctx.cfg.junction_max_num)
+        m12 = np.full(M, -1, np.int32)
+        cnt, npart = C.c_int(0), C.c_int(0)
+        self._chk(self.L.ppg_stereo_match_finish(C.c_void_p(self.h), m12.ctypes.data_as(C.c_void_p), C.byref(cnt), C.byref(npart)))
+        return m12, cnt.value, npart.value
+
     def close(self):
         if getattr(self, "h", None):
             self.L.ppg_shutter_destroy(C.c_void_p(self.h))

@@ -56,6 +56,43 @@ for k in range(6):
     got = ctx.wait_batch()[0][0]
     assert np.array_equal(got["xy"], want["xy"]) and np.array_equal(got["desc"], want["desc"])
 assert sh.drain() == 33
+# swap + left-right match in one call on the resident descriptors (the partner is the rank itself: left = right): the result
+# is the library's own all-pairs claim match of the frame's descriptors with themselves, blocking call and pipeline alike
+try:
+    streams.Shutter.stereo_match(sh, 0, 1)
+    raise SystemExit("a frame outside the last batch must be refused")
+except pkg.PPGError as e:
+    assert "outside" in str(e)
+dense = synth.make_frame(96, 128, 7, 0, "dense")
+for src in ("blocking", "pipeline"):
+    if src == "blocking":
+        fr = ctx.extract(dense)
+    else:
+        ctx.submit_batch([img]); ctx.submit_batch([dense]); ctx.submit_batch([img])
+        ctx.wait_batch()
+        fr = ctx.wait_batch()[0][0]          # another batch is still in flight behind it; its slot stays untouched
+    m12, cnt, npart = sh.stereo_match(0, 0, 0.9)
+    if src == "pipeline":
+        ctx.wait_batch()
+    assert fr["n"] >= 10 and npart == fr["n"], (src, fr["n"], npart)
+    want, _, _, wcnt = ctx.match_nn(fr["desc"], fr["desc"], th=0.7, ratio=0.9, mode=pkg.MATCH_INIT)
+    assert cnt == wcnt and np.array_equal(m12[:fr["n"]], want) and (m12[fr["n"]:] == -1).all(), (src, cnt, wcnt)
+    assert cnt == fr["n"] and np.array_equal(want, np.arange(fr["n"]))     # every row's nearest is itself, at distance 0
+m12, cnt, npart = sh.stereo_match(0, 0, 0.9)          # (the last collected batch is now the one behind the dense frame)
+sh.stereo_match_start(0, 0, 0.9)                    # the two halves: a second start and a swap in between are refused
+for bad in (lambda: sh.stereo_match_start(0, 0, 0.9), lambda: sh.stereo_swap(0, np.zeros((1, 256), np.float32))):
+    try:
+        bad()
+        raise SystemExit("must be refused while a match is pending")
+    except pkg.PPGError:
+        pass
+m12b, cntb, npb = sh.stereo_match_finish()
+assert cntb == cnt and npb == npart and np.array_equal(m12b, m12)
+try:
+    sh.stereo_match_finish()
+    raise SystemExit("nothing was started")
+except pkg.PPGError:
+    pass
 m = pkg.mapped_runtimes()
 assert len(m["amdhip64"]) == 1 and len(m["rccl"]) == 1, m
 sh.close()
