@@ -250,6 +250,18 @@ int main(int argc, char** argv) {
                     fprintf(stderr, "ppg_stereo_swap: %d rows back of %d (%s)\n", nback, n0, ppg_last_error(ext.context()));
                     return 5;
                 }
+                // swap + left-right match in one call on the descriptors still resident from the last run() (frame F[1]); with
+                // the rank as its own partner left = right, so (nearly) every row matches itself
+                const int n1 = (int)F[1].mvKeysUn.size();
+                std::vector<int32_t> lr(PPGExtractor::JUNCTION_MAX_NUM);
+                int nlr = -1, npart = -1;
+                if (ppg_stereo_match(sh, 0, 0, 0.9f, lr.data(), &nlr, &npart) != PPG_OK || npart != n1) {
+                    fprintf(stderr, "ppg_stereo_match: partner rows %d of %d (%s)\n", npart, n1, ppg_last_error(ext.context()));
+                    return 5;
+                }
+                int self = 0;
+                for (int i = 0; i < n1; i++) self += lr[i] == i;
+                if (self * 10 < n1 * 9) { fprintf(stderr, "ppg_stereo_match: %d of %d rows match themselves\n", self, n1); return 5; }
                 ppg_shutter_destroy(sh);
             }
         }
