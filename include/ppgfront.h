@@ -434,8 +434,8 @@ int ppg_shutter_stats(const ppg_shutter* sh, long long* started, int* pending);
  * Both sides call it for every frame, with contexts of the same junction_max_num.  Blocks until the swap is done. */
 int ppg_stereo_swap(ppg_shutter* sh, int partner, const float* desc, int n, float* partner_desc, int* n_partner);
 /* The same swap and the left-right match in one call, for a frame whose descriptors are still on the GPU: frame `frame` of the
- * batch that the last ppg_extract* / ppg_wait_batch on the shutter's context handed out (valid until the second
- * ppg_submit_batch* after that call).  The rows go GPU to GPU (nothing of them crosses PCIe), and this side's rows are
+ * batch that the last ppg_extract* / ppg_wait_batch on the shutter's context handed out (the ring of result slots keeps it
+ * untouched until the next of those calls, whatever is submitted in between).  The rows go GPU to GPU (nothing of them crosses PCIe), and this side's rows are
  * matched against the partner's as Matcher::SearchForInitialization does with a window that holds every feature
  * (matching/src/Matcher.cpp:582-651: all pairs, TH_LOW, `nnratio`), on a matcher context and stream of the shutter's own,
  * beside the extraction pipeline.  matches12: junction_max_num entries (-1 beyond this frame's key points);

@@ -57,6 +57,7 @@ inline int next_slot(int s) { return (s + 1) % kSlots; }
 inline int prev_slot(int s) { return (s + kSlots - 1) % kSlots; }
 struct Slot {
     // device
+    long long uses = 0;           // batches that have been started on this slot
     int* counters = nullptr;      // [B][8]: 0 resid, 1 kept, 2 line candidates, 3 key points
     int32_t* kp_xy = nullptr;
     float *kp_score = nullptr, *kp_un = nullptr, *desc = nullptr, *cand_sc = nullptr;
@@ -223,6 +224,7 @@ struct ppg_ctx {
     // every CU for itself costs the other streams' kernels more than it saves.  PPG_CONV_WS=1: every reduced-precision
     // mode; =0: none (the one-tile-per-work-group kernel the wave-specialised one is checked against).
     int last_out_slot = -1, last_out_n = 0;   // the slot and frame count the last ppg_extract* / ppg_wait_batch handed out
+    long long last_out_use = 0;               // that slot's `uses` then: a later batch on the slot overwrites its device data
     int conv_ws = -1;
     long conv_ws_min_units = 1024;   // (tile, cout block) units a launch needs before it runs wave-specialised (PPG_CONV_WS_MIN)
     bool no_quarter = false;    // PPG_NO_QUARTER_TILES=1: big convolution tiles whatever the batch size (read at ppg_create)

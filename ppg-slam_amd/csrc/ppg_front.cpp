@@ -504,6 +504,8 @@ int ppg_ctx_last_desc(ppg_ctx* c, int frame, const float** d_desc, int* n) {
         return fail(c, PPG_EINVAL, "no extracted batch is resident: call ppg_extract* or ppg_wait_batch first");
     if (frame < 0 || frame >= c->last_out_n) return fail(c, PPG_EINVAL, "frame %d outside the %d frames of the last batch", frame, c->last_out_n);
     const Slot& sl = c->slot[c->last_out_slot];
+    if (sl.uses != c->last_out_use)
+        return fail(c, PPG_EINVAL, "the descriptors of that batch are gone: a later ppg_submit_batch* has taken its slot");
     *d_desc = sl.desc + (size_t)frame * c->maxn * 256;
     *n = sl.nkp[frame];
     return PPG_OK;
@@ -772,7 +774,9 @@ static int create_impl(ppg_ctx* c) {
     std::vector<uint8_t> warm(HW, 1);
     std::vector<const uint8_t*> wp(B, warm.data());
     std::vector<ppg_frame_out> tmp(B);
-    return ppg_extract_batch(c, wp.data(), (int)B, c->W, tmp.data());
+    rc = ppg_extract_batch(c, wp.data(), (int)B, c->W, tmp.data());
+    c->last_out_slot = -1;   // the warm-up frame is nobody's result
+    return rc;
 }
 
 static ppg_ctx* create_common(const ppg_config* cfg, bool matcher_only) {
@@ -860,6 +864,7 @@ int ppg_inference(ppg_ctx* c, const uint8_t* imgs, int n, int on_device) {
             return fail(c, PPG_EINVAL, "four batches are in flight: call ppg_wait_batch first");
         select_lane(c, (c->lane_cur + 1) % c->nlanes);
         select_slot(c, ns);
+        c->slot[ns].uses++;
         c->slot[ns].n = n;
         c->slot[ns].matched = false;
         // nkp keeps the counts of the slot's last collected batch: a later ppg_wait_batch of the OTHER slot
@@ -1056,7 +1061,7 @@ static int finish_slot(ppg_ctx* c, int si, int n, ppg_frame_out* outs) {
                 k[0], k[7] & 255, k[1], k[2], k[3], k[4], k[6], k[7] >> 8);
     }
     for (int b = 0; b < n; b++) sl.nkp[b] = sl.h_counters[b * 8 + 3];
-    c->last_out_slot = si; c->last_out_n = n;
+    c->last_out_slot = si; c->last_out_n = n; c->last_out_use = sl.uses;
     const double t_tail0 = now_ms();
     const int M1 = M + 1;
     // Frames whose line graph the device tail finished point straight into the pinned mirrors.  The others (a value

@@ -12,7 +12,7 @@ PPG_HIDDEN const ppg_config* ppg_ctx_config(const ppg_ctx* ctx);
 PPG_HIDDEN void* ppg_ctx_match_stream(ppg_ctx* ctx);   // hipStream_t of the context's resident matcher
 PPG_HIDDEN int ppg_ctx_raise_match_stream(ppg_ctx* ctx);   // replaces that stream by one of the highest priority
 // device address and row count of the descriptors of frame `frame` of the batch that the last ppg_extract* / ppg_wait_batch
-// on this context handed out (they stay on the GPU until the slot is reused: the second submit after that call)
+// on this context handed out (the slot ring keeps them untouched until the next of those calls)
 PPG_HIDDEN int ppg_ctx_last_desc(ppg_ctx* ctx, int frame, const float** d_desc, int* n);
 // all-pairs claim match of `batch` resident problems on the context's match stream (ppg_match.cpp); counts are device ints
 extern "C" PPG_HIDDEN int match_resident(ppg_ctx* c, const float* dA, const int* nA, const float* dB, const int* nB, int batch,

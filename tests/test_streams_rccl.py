@@ -23,6 +23,11 @@ ctx = pkg.Context(pkg.default_config(128, 96, max_num=64))
 uid = streams.shutter_unique_id()
 assert len(uid) == pkg.SHUTTER_ID_BYTES
 sh = streams.Shutter(ctx, 0, 1, uid)
+try:
+    sh.stereo_match(0, 0, 0.9)
+    raise SystemExit("nothing has been extracted yet: ppg_stereo_match must refuse")
+except pkg.PPGError as e:
+    assert "no extracted batch" in str(e), str(e)
 log = []
 n = streams.run_steps(lambda k: log.append(("s", k)), lambda k: log.append(("w", k)), sh, 0, 25, depth=4)
 assert n == 25 and sh.count == 25
@@ -78,7 +83,18 @@ for src in ("blocking", "pipeline"):
     want, _, _, wcnt = ctx.match_nn(fr["desc"], fr["desc"], th=0.7, ratio=0.9, mode=pkg.MATCH_INIT)
     assert cnt == wcnt and np.array_equal(m12[:fr["n"]], want) and (m12[fr["n"]:] == -1).all(), (src, cnt, wcnt)
     assert cnt == fr["n"] and np.array_equal(want, np.arange(fr["n"]))     # every row's nearest is itself, at distance 0
-m12, cnt, npart = sh.stereo_match(0, 0, 0.9)          # (the last collected batch is now the one behind the dense frame)
+for _ in range(5):                                  # the newest collected batch is always resident, four more in flight or not
+    ctx.submit_batch([img])
+    if _ >= 3:
+        ctx.wait_batch()
+        sh.stereo_match(0, 0, 0.9)
+while True:
+    try:
+        ctx.wait_batch()
+    except pkg.PPGError:
+        break
+fr = ctx.extract(dense)
+m12, cnt, npart = sh.stereo_match(0, 0, 0.9)
 sh.stereo_match_start(0, 0, 0.9)                    # the two halves: a second start and a swap in between are refused
 for bad in (lambda: sh.stereo_match_start(0, 0, 0.9), lambda: sh.stereo_swap(0, np.zeros((1, 256), np.float32))):
     try:
