@@ -1,5 +1,6 @@
 // Multi-GPU mode behind the C ABI: the global-shutter barrier of camera streams sharded over the GPUs of one node, and
-// the point-to-point descriptor swap of a stereo pair split over two GPUs.  RCCL is used directly (no framework in
+// the point-to-point descriptor swap of a stereo pair split over two GPUs, alone (ppg_stereo_swap, host arrays) or together
+// with the left-right match on descriptors that are still on the GPU (ppg_stereo_match).  RCCL is used directly (no framework in
 // between) and is bound at run time: a host that never creates a shutter needs no RCCL installed, and a process that
 // already maps an RCCL image (a framework's bundled copy) keeps using that one image.
 //
